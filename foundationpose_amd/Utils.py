@@ -1,0 +1,320 @@
+"""Host-side helpers with the names and argument meaning of the reference's Utils.py, re-implemented on top of
+libfp_amd.so (device ops) and numpy (init-time setup).  Citations are to /root/reference/Utils.py."""
+import logging
+import random
+
+import numpy as np
+import torch
+
+from . import ops
+from .mesh import SimpleMesh  # noqa: F401  (re-export)
+
+glcam_in_cvcam = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]]).astype(float)  # Utils.py:68-71
+
+
+def set_seed(random_seed):
+    """Utils.py:222-229"""
+    np.random.seed(random_seed)
+    random.seed(random_seed)
+    torch.manual_seed(random_seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(random_seed)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+
+
+# ------------------------------------------------------------------ mesh tensors (Utils.py:104-130)
+def make_mesh_tensors(mesh, device="cuda", max_tex_size=None):
+    """mesh: trimesh-like (``vertices``, ``faces``, ``vertex_normals``, ``visual``).  Returns the reference's dict of
+    device tensors plus '_handle' (the fp_mesh used by the HIP rasteriser)."""
+    visual = getattr(mesh, "visual", None)
+    material = getattr(visual, "material", None)
+    image = getattr(material, "image", None) if material is not None else None
+    t = {}
+    if image is not None and getattr(visual, "uv", None) is not None:
+        img = image.convert("RGB") if hasattr(image, "convert") else image
+        img = np.asarray(img)[..., :3]
+        if max_tex_size is not None and max(img.shape[:2]) > max_tex_size:
+            step = int(np.ceil(max(img.shape[:2]) / max_tex_size))
+            img = img[::step, ::step]  # decimation; the reference uses cv2.resize (Utils.py:110-114, setup-time only)
+        t["tex"] = torch.as_tensor(np.ascontiguousarray(img), device=device, dtype=torch.float)[None] / 255.0
+        t["uv_idx"] = torch.as_tensor(np.asarray(mesh.faces), device=device, dtype=torch.int)
+        uv = torch.as_tensor(np.asarray(visual.uv), device=device, dtype=torch.float)
+        uv[:, 1] = 1 - uv[:, 1]
+        t["uv"] = uv
+    else:
+        vc = getattr(visual, "vertex_colors", None) if visual is not None else None
+        if vc is None:
+            logging.info("WARN: mesh doesn't have vertex_colors, assigning a pure color")
+            vc = np.tile(np.array([128, 128, 128]).reshape(1, 3), (len(mesh.vertices), 1))
+            if visual is not None:
+                try:
+                    visual.vertex_colors = vc  # the reference mutates the mesh too (Utils.py:120-122)
+                except Exception:
+                    pass
+        t["vertex_color"] = torch.as_tensor(np.asarray(vc)[..., :3], device=device, dtype=torch.float) / 255.0
+    t["pos"] = torch.tensor(np.asarray(mesh.vertices), device=device, dtype=torch.float)
+    t["faces"] = torch.tensor(np.asarray(mesh.faces), device=device, dtype=torch.int)
+    t["vnormals"] = torch.tensor(np.asarray(mesh.vertex_normals), device=device, dtype=torch.float)
+    t["_handle"] = mesh_handle_from_tensors(t)
+    return t
+
+
+def mesh_handle_from_tensors(t):
+    return ops.MeshHandle(t["pos"].contiguous(), t["vnormals"].contiguous(), t["faces"].contiguous(),
+                          uv=t["uv"].contiguous() if "uv" in t else None,
+                          uv_idx=t["uv_idx"].contiguous() if "uv_idx" in t else None,
+                          tex=t["tex"].contiguous() if "tex" in t else None,
+                          vertex_color=t["vertex_color"].contiguous() if "vertex_color" in t else None)
+
+
+def get_mesh_handle(mesh_tensors):
+    h = mesh_tensors.get("_handle")
+    if h is None or h.device != mesh_tensors["pos"].device or h.pos.data_ptr() != mesh_tensors["pos"].data_ptr():
+        h = mesh_handle_from_tensors(mesh_tensors)
+        mesh_tensors["_handle"] = h
+    return h
+
+
+# ------------------------------------------------------------------ render (Utils.py:133-219)
+def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, glctx=None, context="cuda", get_normal=False,
+                      mesh_tensors=None, mesh=None, projection_mat=None, bbox2d=None, output_size=None,
+                      use_light=False, light_color=None, light_dir=np.array([0, 0, 1]), light_pos=np.array([0, 0, 0]),
+                      w_ambient=0.8, w_diffuse=0.5, extra={}):
+    """Same contract as the reference wrapper: returns (color (N,h,w,3) in [0,1], depth (N,h,w), normal_map or None)
+    and fills extra['xyz_map'].  Rasterisation, interpolation, texturing, shading and the Y flips are one HIP kernel."""
+    if context not in ("cuda", "gl"):
+        raise NotImplementedError
+    if projection_mat is not None:
+        raise NotImplementedError("custom projection_mat is not supported; the projection is derived from K,H,W")
+    if light_color is not None or light_dir is None:
+        raise NotImplementedError("only the default directional light of the hot path is implemented")
+    if mesh_tensors is None:
+        mesh_tensors = make_mesh_tensors(mesh)
+    handle = get_mesh_handle(mesh_tensors)
+    poses = torch.as_tensor(ob_in_cams, device=handle.device, dtype=torch.float).reshape(-1, 4, 4).contiguous()
+    if output_size is None:
+        output_size = (H, W)
+    bb = None
+    if bbox2d is not None:
+        bb = torch.as_tensor(bbox2d, device=handle.device, dtype=torch.float).reshape(-1, 4)
+        if bb.shape[0] != poses.shape[0]:
+            bb = bb.expand(poses.shape[0], 4)
+        bb = bb.contiguous()
+    elif (int(output_size[0]), int(output_size[1])) != (int(H), int(W)):
+        raise NotImplementedError("output_size != (H,W) needs bbox2d")
+    if use_light:
+        get_normal = True
+    want = ["color", "depth", "xyz"] + (["normal"] if get_normal else [])
+    # without lighting the reference returns the unshaded base colour: ambient 1, diffuse 0
+    wa, wd = (w_ambient, w_diffuse) if use_light else (1.0, 0.0)
+    outs = []
+    for b in range(0, poses.shape[0], 4096):
+        outs.append(ops.render_crops(handle, poses[b:b + 4096], None if bb is None else bb[b:b + 4096], K, H, W,
+                                     out_hw=(int(output_size[0]), int(output_size[1])), want=want, w_ambient=wa,
+                                     w_diffuse=wd))
+    cat = (lambda k: outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], dim=0))
+    extra["xyz_map"] = cat("xyz")
+    return cat("color"), cat("depth"), (cat("normal") if get_normal else None)
+
+
+# ------------------------------------------------------------------ depth filters / back-projection
+def _to_dev_f32(x, device="cuda"):
+    return torch.as_tensor(x, dtype=torch.float, device=device).contiguous()
+
+
+def erode_depth(depth, radius=2, depth_diff_thres=0.001, ratio_thres=0.8, zfar=100, device="cuda"):
+    """Utils.py:387-395: numpy in => numpy out, tensor in => tensor out."""
+    out = ops.erode_depth(_to_dev_f32(depth, device), radius, depth_diff_thres, ratio_thres, float(zfar))
+    return out.data.cpu().numpy() if isinstance(depth, np.ndarray) else out
+
+
+def bilateral_filter_depth(depth, radius=2, zfar=100, sigmaD=2, sigmaR=100000, device="cuda"):
+    """Utils.py:345-356"""
+    out = ops.bilateral_filter_depth(_to_dev_f32(depth, device), radius, float(zfar), float(sigmaD), float(sigmaR))
+    return out.data.cpu().numpy() if isinstance(depth, np.ndarray) else out
+
+
+def depth2xyzmap(depth, K, uvs=None):
+    """Utils.py:399-417 (float64 intrinsics).  numpy in => numpy out, tensor in => tensor out."""
+    if uvs is not None:
+        raise NotImplementedError("sparse uvs are not on the hot path")
+    out = ops.depth_to_xyz(_to_dev_f32(depth), K, zfar=float("inf"), f64_internal=True)
+    return out.data.cpu().numpy() if isinstance(depth, np.ndarray) else out
+
+
+def depth2xyzmap_batch(depths, Ks, zfar):
+    """Utils.py:420-438: depths (B,H,W) tensor, Ks (B,3,3) tensor -> (B,H,W,3)."""
+    depths = _to_dev_f32(depths)
+    Ks = torch.as_tensor(Ks).detach().cpu().numpy()
+    return torch.stack([ops.depth_to_xyz(depths[b], Ks[b], zfar=float(zfar), f64_internal=False)
+                        for b in range(depths.shape[0])], dim=0)
+
+
+# ------------------------------------------------------------------ small transforms
+def to_homo_torch(pts):
+    ones = torch.ones((*pts.shape[:-1], 1), dtype=torch.float, device=pts.device)
+    return torch.cat((pts, ones), dim=-1)
+
+
+def transform_pts(pts, tf):
+    """Utils.py:529-536"""
+    if len(tf.shape) >= 3 and tf.shape[-3] != pts.shape[-2]:
+        tf = tf[..., None, :, :]
+    return (tf[..., :-1, :-1] @ pts[..., None] + tf[..., :-1, -1:])[..., 0]
+
+
+def transform_dirs(dirs, tf):
+    """Utils.py:539-546"""
+    if len(tf.shape) >= 3 and tf.shape[-3] != dirs.shape[-2]:
+        tf = tf[..., None, :, :]
+    return (tf[..., :3, :3] @ dirs[..., None])[..., 0]
+
+
+def egocentric_delta_pose_to_pose(A_in_cam, trans_delta, rot_mat_delta):
+    """Utils.py:848-855"""
+    B_in_cam = torch.eye(4, dtype=torch.float, device=A_in_cam.device)[None].expand(len(A_in_cam), -1, -1).contiguous()
+    B_in_cam[:, :3, 3] = A_in_cam[:, :3, 3] + trans_delta
+    B_in_cam[:, :3, :3] = rot_mat_delta @ A_in_cam[:, :3, :3]
+    return B_in_cam
+
+
+def compute_crop_window_tf_batch(pts=None, H=None, W=None, poses=None, K=None, crop_ratio=1.2, out_size=None, rgb=None,
+                                 uvs=None, method="min_box", mesh_diameter=None):
+    """Utils.py:577-626 (only method='box_3d' exists there).  Returns tf_to_crops (B,3,3) on the device."""
+    if method != "box_3d":
+        raise RuntimeError
+    poses = torch.as_tensor(poses, dtype=torch.float, device="cuda").reshape(-1, 4, 4).contiguous()
+    tf, _ = ops.crop_windows(poses, K, mesh_diameter, crop_ratio, out_size)
+    return tf
+
+
+def projection_matrix_from_intrinsics(K, height, width, znear, zfar, window_coords="y_down"):
+    """Utils.py:752-802 (kept for API completeness; the HIP rasteriser projects with K directly)."""
+    K = np.asarray(K, dtype=float)
+    depth = float(zfar - znear)
+    q = -(zfar + znear) / depth
+    qn = -2 * (zfar * znear) / depth
+    if window_coords == "y_up":
+        r1 = [0, -2 * K[1, 1] / height, (-2 * K[1, 2] + height) / height, 0]
+    elif window_coords == "y_down":
+        r1 = [0, 2 * K[1, 1] / height, (2 * K[1, 2] - height) / height, 0]
+    else:
+        raise NotImplementedError
+    return np.array([[2 * K[0, 0] / width, -2 * K[0, 1] / width, (-2 * K[0, 2] + width) / width, 0], r1,
+                     [0, 0, q, qn], [0, 0, -1, 0]])
+
+
+# ------------------------------------------------------------------ hypothesis-generation setup (CPU, init time)
+def euler_matrix(ai, aj, ak, axes="sxyz"):
+    """Static-xyz Euler angles -> 4x4 (what transformations.euler_matrix returns for the default axes)."""
+    if axes != "sxyz":
+        raise NotImplementedError
+    ci, si, cj, sj, ck, sk = np.cos(ai), np.sin(ai), np.cos(aj), np.sin(aj), np.cos(ak), np.sin(ak)
+    Rx = np.array([[1, 0, 0], [0, ci, -si], [0, si, ci]])
+    Ry = np.array([[cj, 0, sj], [0, 1, 0], [-sj, 0, cj]])
+    Rz = np.array([[ck, -sk, 0], [sk, ck, 0], [0, 0, 1]])
+    M = np.eye(4)
+    M[:3, :3] = Rz @ Ry @ Rx
+    return M
+
+
+def icosphere_vertices(subdivisions=1):
+    """Unit icosphere vertices (12 icosahedron vertices, then edge midpoints per subdivision level).
+    Vertex ORDER differs from trimesh.creation.icosphere; it only permutes the hypothesis order."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+         [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]]
+    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+         [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
+         [8, 6, 7], [9, 8, 1]]
+    v = [np.asarray(p, dtype=float) / np.linalg.norm(p) for p in v]
+    for _ in range(subdivisions):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = (v[a] + v[b]) / 2.0
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        f = nf
+    return np.asarray(v)
+
+
+def sample_views_icosphere(n_views, subdivisions=None, radius=1):
+    """Utils.py:483-507: camera-in-object poses looking at the origin from icosphere vertices."""
+    if subdivisions is None:
+        subdivisions = 1
+        while icosphere_vertices(subdivisions).shape[0] < n_views:
+            subdivisions += 1
+    verts = icosphere_vertices(subdivisions) * radius
+    cam_in_obs = np.tile(np.eye(4)[None], (len(verts), 1, 1))
+    cam_in_obs[:, :3, 3] = verts
+    up = np.array([0, 0, 1])
+    z_axis = -cam_in_obs[:, :3, 3]
+    z_axis /= np.linalg.norm(z_axis, axis=-1).reshape(-1, 1)
+    x_axis = np.cross(up.reshape(1, 3), z_axis)
+    invalid = (x_axis == 0).all(axis=-1)
+    x_axis[invalid] = [1, 0, 0]
+    x_axis /= np.linalg.norm(x_axis, axis=-1).reshape(-1, 1)
+    y_axis = np.cross(z_axis, x_axis)
+    y_axis /= np.linalg.norm(y_axis, axis=-1).reshape(-1, 1)
+    cam_in_obs[:, :3, 0] = x_axis
+    cam_in_obs[:, :3, 1] = y_axis
+    cam_in_obs[:, :3, 2] = z_axis
+    return cam_in_obs
+
+
+def compute_mesh_diameter(model_pts=None, mesh=None, n_sample=1000):
+    """Utils.py:559-574: max pairwise distance of (a random subset of) the points; returns np.float64."""
+    if mesh is not None:
+        model_pts = np.asarray(mesh.vertices)
+    pts = np.asarray(model_pts, dtype=np.float64)
+    if n_sample is not None:
+        ids = np.random.choice(len(pts), size=min(n_sample, len(pts)), replace=False)
+        pts = pts[ids]
+    best = 0.0
+    for i in range(0, len(pts), 1024):
+        d = np.linalg.norm(pts[None] - pts[i:i + 1024, None], axis=-1)
+        best = max(best, d.max())
+    return np.float64(best)
+
+
+def symmetry_tfs_from_info(info, rot_angle_discrete=5):
+    """Utils.py:806-834 (BOP models_info symmetries -> list of 4x4)."""
+    symmetry_tfs = [np.eye(4)]
+    if "symmetries_discrete" in info:
+        tfs = np.array(info["symmetries_discrete"]).reshape(-1, 4, 4)
+        tfs[..., :3, 3] *= 0.001
+        symmetry_tfs = [np.eye(4)] + list(tfs)
+    if "symmetries_continuous" in info:
+        axis = np.array(info["symmetries_continuous"][0]["axis"]).reshape(3)
+        offset = info["symmetries_continuous"][0]["offset"]
+        rxs, rys, rzs = [0], [0], [0]
+        steps = np.arange(0, 360, rot_angle_discrete) / 180.0 * np.pi
+        if axis[0] > 0:
+            rxs = steps
+        elif axis[1] > 0:
+            rys = steps
+        elif axis[2] > 0:
+            rzs = steps
+        for rx in rxs:
+            for ry in rys:
+                for rz in rzs:
+                    tf = euler_matrix(rx, ry, rz)
+                    tf[:3, 3] = offset
+                    symmetry_tfs.append(tf)
+    return np.array(symmetry_tfs)
+
+
+def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
+    """mycpp.cluster_poses look-alike (mycpp/src/app/pybind_api.cpp:24-68): returns the kept poses."""
+    poses_in = np.asarray(poses_in)
+    keep = ops.cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs)
+    return poses_in[keep]

@@ -1,0 +1,125 @@
+// Observed-frame crop kernel (B side): replaces the kornia warp_perspective call sites
+// (predict_pose_refine.py:63,72 ; predict_score.py:89-90), the dataset normalisation
+// (h5_dataset.py:79-114 refine, :137-170 score incl. the depth -> frame -> xyz -> crop chain) and the
+// channel concat (predict_pose_refine.py:188).  The warp is always scale+translate, so the source
+// coordinates are affine in (i, j); one lane per output pixel, consecutive lanes = consecutive i, which makes
+// both the frame reads (a few adjacent texels per wave, L2 resident: the frame is 3.7 MB) and the planar
+// NCHW stores coalesced.  Compiled with -ffp-contract=off (definition shared with oracle/fp_oracle.c).
+#include <hip/hip_fp16.h>
+#include "fp_common.h"
+
+__device__ __forceinline__ int nn_index(float x) { return (int)rintf(x); }  // half-to-even like grid_sample nearest
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_warp(const float* __restrict__ rgb, const float* __restrict__ xyz_map,
+                                              const float* __restrict__ depthf, const float* __restrict__ tfs,
+                                              fp_k9 K, const float* __restrict__ poses, float inv_r, int flags,
+                                              int H, int W, int oh, int ow, void* __restrict__ Bout) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int npx = oh * ow;
+  if (p >= npx) return;
+  const int j = p / ow, i = p - j * ow;
+  const float* tf = tfs + (size_t)n * 9;
+  const float sx = tf[0], tx = tf[2], sy = tf[4], ty = tf[5];
+  const float i00 = 1.0f / sx, i11 = 1.0f / sy;
+  const float i02 = (-tx) / sx, i12 = (-ty) / sy;
+  const float cW = (float)W / (float)(W - 1), cH = (float)H / (float)(H - 1);
+  const float xs = fmaf((float)i, i00, i02), ys = fmaf((float)j, i11, i12);
+  const float ix = fmaf(xs, cW, -0.5f), iy = fmaf(ys, cH, -0.5f);
+  float a[6];
+  // ---- rgb, bilinear with zero padding (tap order nw, ne, sw, se as torch grid_sample)
+  {
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+    const float wne = (ix - (float)x0) * ((float)y1 - iy);
+    const float wsw = ((float)x1 - ix) * (iy - (float)y0);
+    const float wse = (ix - (float)x0) * (iy - (float)y0);
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      if (vx0 && vy0) acc += rgb[((size_t)y0 * W + x0) * 3 + c] * wnw;
+      if (vx1 && vy0) acc += rgb[((size_t)y0 * W + x1) * 3 + c] * wne;
+      if (vx0 && vy1) acc += rgb[((size_t)y1 * W + x0) * 3 + c] * wsw;
+      if (vx1 && vy1) acc += rgb[((size_t)y1 * W + x1) * 3 + c] * wse;
+      a[c] = acc / 255.0f;
+    }
+  }
+  // ---- xyz, nearest
+  float pt[3] = {0.f, 0.f, 0.f};
+  const int qx = nn_index(ix), qy = nn_index(iy);
+  const bool q_in = qx >= 0 && qx < W && qy >= 0 && qy < H;
+  if (MODE == FP_MODE_REFINE) {
+    if (q_in) {
+      const float* s = xyz_map + ((size_t)qy * W + qx) * 3;
+      pt[0] = s[0]; pt[1] = s[1]; pt[2] = s[2];
+    }
+  } else if (q_in) {
+    const float cSw = (float)ow / (float)(ow - 1), cSh = (float)oh / (float)(oh - 1);
+    const float ccx = fmaf(sx, (float)qx, tx), ccy = fmaf(sy, (float)qy, ty);
+    const int px = nn_index(fmaf(ccx, cSw, -0.5f)), py = nn_index(fmaf(ccy, cSh, -0.5f));
+    float z = 0.f;
+    if (px >= 0 && px < ow && py >= 0 && py < oh) {
+      const float xs2 = fmaf((float)px, i00, i02), ys2 = fmaf((float)py, i11, i12);
+      const int rx = nn_index(fmaf(xs2, cW, -0.5f)), ry = nn_index(fmaf(ys2, cH, -0.5f));
+      if (rx >= 0 && rx < W && ry >= 0 && ry < H) z = depthf[(size_t)ry * W + rx];
+    }
+    if (!(z < 0.001f)) {
+      pt[0] = (((float)qx - K.v[2]) * z) / K.v[0];
+      pt[1] = (((float)qy - K.v[5]) * z) / K.v[4];
+      pt[2] = z;
+    }
+  }
+  const float* P = poses + (size_t)n * 16;
+  const float thr = (MODE == FP_MODE_SCORE) ? 0.1f : 0.001f;
+  const bool normalize = (flags & FP_FLAG_NORMALIZE_XYZ) != 0;
+  const bool invalid = pt[2] < thr;
+  const float d[3] = {pt[0] - P[3], pt[1] - P[7], pt[2] - P[11]};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float val = d[c];
+    if (normalize) {
+      val = val * inv_r;
+      if (invalid || fabsf(val) >= 2.0f) val = 0.f;
+    }
+    a[3 + c] = val;
+  }
+  const size_t o = (size_t)n * 6 * npx + p;
+  if (flags & FP_FLAG_OUT_F16) {
+    __half* B = reinterpret_cast<__half*>(Bout);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) B[o + (size_t)c * npx] = __float2half_rn(a[c]);
+  } else {
+    float* B = reinterpret_cast<float*>(Bout);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) B[o + (size_t)c * npx] = a[c];
+  }
+}
+
+extern "C" int fp_warp_crops(const float* rgb, const float* xyz_map, const float* depth, const float* tf_to_crops,
+                             const float* K9, const float* poses, float mesh_diameter, int flags, int mode, int H,
+                             int W, int N, int oh, int ow, void* B, void* stream) {
+  FP_REQUIRE(N >= 0, "fp_warp_crops: N < 0");
+  if (N == 0) return FP_OK;
+  FP_REQUIRE(rgb && tf_to_crops && K9 && poses && B, "fp_warp_crops: NULL tensor");
+  FP_REQUIRE(H > 1 && W > 1 && oh > 1 && ow > 1, "fp_warp_crops: degenerate sizes");
+  FP_REQUIRE(N <= 65535, "fp_warp_crops: N=%d exceeds the grid limit; chunk the batch", N);
+  FP_REQUIRE(mode == FP_MODE_REFINE || mode == FP_MODE_SCORE, "fp_warp_crops: unknown mode %d", mode);
+  FP_REQUIRE(mode != FP_MODE_REFINE || xyz_map, "fp_warp_crops: REFINE mode needs xyz_map");
+  FP_REQUIRE(mode != FP_MODE_SCORE || depth, "fp_warp_crops: SCORE mode needs depth");
+  fp_k9 K;
+  for (int i = 0; i < 9; ++i) K.v[i] = K9[i];
+  const float inv_r = 1.0f / (mesh_diameter * 0.5f);
+  dim3 grid(fp_cdiv(oh * ow, 256), N), block(256);
+  if (mode == FP_MODE_REFINE)
+    hipLaunchKernelGGL(k_warp<FP_MODE_REFINE>, grid, block, 0, (hipStream_t)stream, rgb, xyz_map, depth, tf_to_crops,
+                       K, poses, inv_r, flags, H, W, oh, ow, B);
+  else
+    hipLaunchKernelGGL(k_warp<FP_MODE_SCORE>, grid, block, 0, (hipStream_t)stream, rgb, xyz_map, depth, tf_to_crops,
+                       K, poses, inv_r, flags, H, W, oh, ow, B);
+  FP_CHECK_LAUNCH("fp_warp_crops");
+  return FP_OK;
+}

@@ -1,0 +1,188 @@
+"""Inference plans for RefineNet / ScoreNetMultiPair on PyTorch-ROCm.
+
+A plan is built once from a module's state_dict (reference checkpoints load unchanged): eval-mode BatchNorm is
+folded into the preceding conv, weights are cast to the compute dtype, and the two layers the north-star names are
+routed to hand-written MFMA kernels of libfp_amd.so (fp16 plans only):
+  * patch-embed conv  (7x7 s2, 6->64 + BN + ReLU)  -> fp_conv7x7s2_bn_relu_fwd
+  * QKV in_proj (512->1536) and the other 512-wide projections -> fp_linear_f16_fwd
+Everything else is PyTorch-ROCm (MIOpen convs, hipBLASLt GEMMs).  precision='fp32' is the parity configuration
+(all torch ops, fp32, no autocast); precision='fp16' mirrors the reference's autocast(fp16) deployment
+(predict_pose_refine.py:190, predict_score.py:193).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _fold_bn(sd, conv_p, bn_p):
+    w = sd[conv_p + ".weight"].float()
+    b = sd.get(conv_p + ".bias")
+    b = torch.zeros(w.shape[0], device=w.device) if b is None else b.float()
+    if bn_p is not None and (bn_p + ".weight") in sd:
+        scale = sd[bn_p + ".weight"].float() / torch.sqrt(sd[bn_p + ".running_var"].float() + 1e-5)
+        shift = (b - sd[bn_p + ".running_mean"].float()) * scale + sd[bn_p + ".bias"].float()
+        return w, scale, shift
+    return w, torch.ones_like(b), b
+
+
+class _Conv:
+    """conv (+folded BN) (+ReLU); weights pre-scaled so the epilogue is bias-only."""
+
+    def __init__(self, sd, conv_p, bn_p, stride, dtype, channels_last):
+        w, scale, shift = _fold_bn(sd, conv_p, bn_p)
+        self.raw_w, self.scale, self.shift = w, scale.contiguous(), shift.contiguous()
+        wf = (w * scale[:, None, None, None]).to(dtype)
+        self.w = wf.contiguous(memory_format=torch.channels_last) if channels_last else wf.contiguous()
+        self.b = shift.to(dtype)
+        self.stride = stride
+        self.pad = (w.shape[-1] - 1) // 2
+
+    def __call__(self, x, relu=True):
+        y = F.conv2d(x, self.w, self.b, stride=self.stride, padding=self.pad)
+        return F.relu_(y) if relu else y
+
+
+class _Block:
+    def __init__(self, sd, p, dtype, cl):
+        self.c1 = _Conv(sd, p + ".conv1", p + ".bn1", 1, dtype, cl)
+        self.c2 = _Conv(sd, p + ".conv2", p + ".bn2", 1, dtype, cl)
+
+    def __call__(self, x):
+        y = self.c2(self.c1(x), relu=False)
+        y += x
+        return F.relu_(y)
+
+
+class _Encoder:
+    """stem on cat(A,B) along batch + joint encoder on the channel concat -> tokens (N,400,512) + PE."""
+
+    def __init__(self, sd, stem, joint, dtype, channels_last, use_hip):
+        cl = channels_last
+        self.dtype, self.cl, self.use_hip = dtype, cl, use_hip and dtype == torch.float16
+        self.c1 = _Conv(sd, stem + ".0.net.0", stem + ".0.net.1", 2, dtype, cl)
+        if self.use_hip:
+            self.c1_wflat = self.c1.raw_w.to(torch.float16).reshape(64, -1).contiguous()
+        self.c2 = _Conv(sd, stem + ".1.net.0", stem + ".1.net.1", 2, dtype, cl)
+        self.s2, self.s3 = _Block(sd, stem + ".2", dtype, cl), _Block(sd, stem + ".3", dtype, cl)
+        self.j0, self.j1 = _Block(sd, joint + ".0", dtype, cl), _Block(sd, joint + ".1", dtype, cl)
+        self.j2 = _Conv(sd, joint + ".2.net.0", joint + ".2.net.1", 2, dtype, cl)
+        self.j3, self.j4 = _Block(sd, joint + ".3", dtype, cl), _Block(sd, joint + ".4", dtype, cl)
+        self.pe = sd["pos_embed.pe"].to(dtype)
+
+    def __call__(self, AB):
+        """AB: (2N,6,H,W) -- A in the first half, B in the second."""
+        n = AB.shape[0] // 2
+        if self.use_hip:
+            x = ops.conv7x7s2_bn_relu(AB, self.c1_wflat, self.c1.scale, self.c1.shift, channels_last=self.cl)
+        else:
+            if self.cl:
+                AB = AB.contiguous(memory_format=torch.channels_last)
+            x = self.c1(AB)
+        x = self.s3(self.s2(self.c2(x)))
+        ab = torch.cat((x[:n], x[n:]), dim=1)
+        ab = self.j4(self.j3(self.j2(self.j1(self.j0(ab)))))
+        tok = ab.permute(0, 2, 3, 1).reshape(n, -1, ab.shape[1])  # free view when channels_last
+        return tok + self.pe[:, : tok.shape[1]]
+
+
+class _Linear:
+    def __init__(self, w, b, dtype, use_hip):
+        self.use_hip = use_hip and dtype == torch.float16 and w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0
+        self.w = w.to(dtype).contiguous()
+        self.b32 = b.float().contiguous()
+        self.b = b.to(dtype)
+
+    def __call__(self, x, relu=False):
+        if self.use_hip:
+            return ops.linear_f16(x.contiguous(), self.w, self.b32, relu=relu)
+        y = F.linear(x, self.w, self.b)
+        return F.relu_(y) if relu else y
+
+
+class _MHA:
+    """self-attention of nn.MultiheadAttention(512, 4, batch_first=True) called as att(x, x, x)."""
+
+    def __init__(self, sd, p, dtype, use_hip, nhead=4):
+        self.qkv = _Linear(sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"], dtype, use_hip)
+        self.out = _Linear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"], dtype, use_hip)
+        self.nhead = nhead
+
+    def __call__(self, x):
+        Bn, L, D = x.shape
+        hd = D // self.nhead
+        qkv = self.qkv(x).reshape(Bn, L, 3, self.nhead, hd)
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        att = torch.softmax((q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd)), dim=-1)
+        o = (att @ v).permute(0, 2, 1, 3).reshape(Bn, L, D)
+        return self.out(o)
+
+
+class _EncoderLayer:
+    """nn.TransformerEncoderLayer(512, 4, 512, batch_first=True) in eval mode: post-norm, ReLU, LN eps 1e-5 (fp32)."""
+
+    def __init__(self, sd, p, dtype, use_hip):
+        self.att = _MHA(sd, p + ".self_attn", dtype, use_hip)
+        self.l1 = _Linear(sd[p + ".linear1.weight"], sd[p + ".linear1.bias"], dtype, use_hip)
+        self.l2 = _Linear(sd[p + ".linear2.weight"], sd[p + ".linear2.bias"], dtype, use_hip)
+        self.n1 = (sd[p + ".norm1.weight"].float(), sd[p + ".norm1.bias"].float())
+        self.n2 = (sd[p + ".norm2.weight"].float(), sd[p + ".norm2.bias"].float())
+        self.dtype = dtype
+
+    def _ln(self, x, wb):
+        return F.layer_norm(x.float(), (x.shape[-1],), wb[0], wb[1], 1e-5).to(self.dtype)
+
+    def __call__(self, x):
+        x = self._ln(x + self.att(x), self.n1)
+        return self._ln(x + self.l2(self.l1(x, relu=True)), self.n2)
+
+
+def _dev_sd(module_or_sd, device):
+    sd = module_or_sd.state_dict() if hasattr(module_or_sd, "state_dict") else module_or_sd
+    return {k: v.detach().to(device) for k, v in sd.items()}
+
+
+class RefinePlan:
+    def __init__(self, model, device, precision="fp16", channels_last=True, use_hip=True):
+        sd = _dev_sd(model, device)
+        self.dtype = torch.float16 if precision == "fp16" else torch.float32
+        self.enc = _Encoder(sd, "encodeA", "encodeAB", self.dtype, channels_last, use_hip)
+        self.heads = {}
+        for name in ("trans", "rot"):
+            self.heads[name] = (_EncoderLayer(sd, f"{name}_head.0", self.dtype, use_hip),
+                                sd[f"{name}_head.1.weight"].to(self.dtype), sd[f"{name}_head.1.bias"].to(self.dtype))
+
+    @torch.inference_mode()
+    def __call__(self, AB):
+        tok = self.enc(AB)
+        out = {}
+        for name, (layer, w, b) in self.heads.items():
+            out[name] = F.linear(layer(tok), w, b).float().mean(dim=1)
+        return out
+
+
+class ScorePlan:
+    def __init__(self, model, device, precision="fp16", channels_last=True, use_hip=True):
+        sd = _dev_sd(model, device)
+        self.dtype = torch.float16 if precision == "fp16" else torch.float32
+        self.enc = _Encoder(sd, "encoderA", "encoderAB", self.dtype, channels_last, use_hip)
+        self.att = _MHA(sd, "att", self.dtype, use_hip)
+        self.att_cross = _MHA(sd, "att_cross", self.dtype, use_hip)
+        self.lin_w, self.lin_b = sd["linear.weight"].to(self.dtype), sd["linear.bias"].to(self.dtype)
+
+    @torch.inference_mode()
+    def features(self, AB):
+        """(2n,6,H,W) -> pooled per-hypothesis features (n,512) (score_network.py:60-74)."""
+        return self.att(self.enc(AB)).float().mean(dim=1).to(self.dtype)
+
+    @torch.inference_mode()
+    def head(self, feats, L):
+        """cross-hypothesis attention + linear (score_network.py:83-88): feats (bs*L,512) -> logits (bs,L) fp32."""
+        x = feats.reshape(-1, L, feats.shape[-1])
+        x = self.att_cross(x)
+        return F.linear(x, self.lin_w, self.lin_b).float().reshape(-1, L)
+
+    def __call__(self, AB, L):
+        return {"score_logit": self.head(self.features(AB), L)}

@@ -1,0 +1,254 @@
+"""torch-tensor front-end of the C ABI (device pointers + current HIP stream).  Plumbing only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FLAG_NORMALIZE_XYZ = 1
+FLAG_OUT_F16 = 2
+MODE_REFINE = 0
+MODE_SCORE = 1
+ROT_AXIS_ANGLE = 0
+ROT_6D = 1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name):
+    if t is None:
+        return None
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise _lib.FpAmdError(f"{name}: expected a CUDA(HIP) tensor; there is no CPU path in foundationpose_amd")
+    if t.dtype != dtype:
+        raise _lib.FpAmdError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.FpAmdError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _hostK64(K):
+    return np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
+
+
+def _hostK32(K):
+    if torch.is_tensor(K):
+        K = K.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9).astype(np.float32))
+
+
+class MeshHandle:
+    """Device mesh tensors + the fp_mesh handle (Utils.py:104-130 make_mesh_tensors)."""
+
+    def __init__(self, pos, vnormals, faces, uv=None, uv_idx=None, tex=None, vertex_color=None):
+        self.pos = _dev(pos, torch.float32, "pos")
+        self.vnormals = _dev(vnormals, torch.float32, "vnormals")
+        self.faces = _dev(faces, torch.int32, "faces")
+        self.uv = _dev(uv, torch.float32, "uv")
+        self.uv_idx = _dev(uv_idx, torch.int32, "uv_idx")
+        self.tex = _dev(tex, torch.float32, "tex")
+        self.vertex_color = _dev(vertex_color, torch.float32, "vertex_color")
+        self.V, self.T = int(pos.shape[0]), int(faces.shape[0])
+        Ht = Wt = 0
+        if self.tex is not None:
+            Ht, Wt = int(self.tex.shape[-3]), int(self.tex.shape[-2])
+        h = C.c_void_p()
+        st = _lib.lib().fp_mesh_create(_ptr(self.pos), _ptr(self.vnormals), _ptr(self.faces), _ptr(self.uv),
+                                       _ptr(self.uv_idx), _ptr(self.tex), _ptr(self.vertex_color), self.V, self.T,
+                                       Ht, Wt, C.byref(h))
+        _lib.check(st, "fp_mesh_create")
+        self.handle = h
+        self.device = self.pos.device
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().fp_mesh_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def erode_depth(depth, radius=2, depth_diff_thres=0.001, ratio_thres=0.8, zfar=100.0):
+    d = _dev(depth, torch.float32, "depth")
+    out = torch.empty_like(d)
+    H, W = d.shape
+    _lib.check(_lib.lib().fp_depth_erode(_ptr(d), _ptr(out), H, W, int(radius), depth_diff_thres, ratio_thres, zfar,
+                                         _stream()), "fp_depth_erode")
+    return out
+
+
+def bilateral_filter_depth(depth, radius=2, zfar=100.0, sigmaD=2.0, sigmaR=100000.0):
+    d = _dev(depth, torch.float32, "depth")
+    out = torch.empty_like(d)
+    H, W = d.shape
+    _lib.check(_lib.lib().fp_depth_bilateral(_ptr(d), _ptr(out), H, W, int(radius), zfar, sigmaD, sigmaR, _stream()),
+               "fp_depth_bilateral")
+    return out
+
+
+def depth_to_xyz(depth, K, zfar=float("inf"), f64_internal=False):
+    d = _dev(depth, torch.float32, "depth")
+    H, W = d.shape
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=d.device)
+    Kd = _hostK64(K)
+    _lib.check(_lib.lib().fp_depth_to_xyz(_ptr(d), Kd.ctypes.data_as(C.c_void_p), float(zfar), int(bool(f64_internal)),
+                                          _ptr(out), H, W, _stream()), "fp_depth_to_xyz")
+    return out
+
+
+def crop_windows(poses, K, mesh_diameter, crop_ratio, out_size=(160, 160)):
+    """-> tf_to_crops (N,3,3) f32, bbox2d (N,4) f32.  out_size = (width, height)."""
+    P = _dev(poses, torch.float32, "poses")
+    N = int(P.shape[0])
+    tf = torch.empty((N, 3, 3), dtype=torch.float32, device=P.device)
+    bb = torch.empty((N, 4), dtype=torch.float32, device=P.device)
+    Kd = _hostK64(K)
+    _lib.check(_lib.lib().fp_crop_windows(_ptr(P), Kd.ctypes.data_as(C.c_void_p), float(mesh_diameter),
+                                          float(crop_ratio), int(out_size[0]), int(out_size[1]), N, _ptr(tf), _ptr(bb),
+                                          _stream()), "fp_crop_windows")
+    return tf, bb
+
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    if nbytes == 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def render_crops(mesh, poses, bbox2d, K, H, W, out_hw=(160, 160), mesh_diameter=1.0, xyz_thr=0.001,
+                 normalize_xyz=True, out_f16=False, w_ambient=0.8, w_diffuse=0.5,
+                 want=("A",), A_out=None):
+    """Fused render of N hypotheses (see fp_render_crops).  Returns dict of requested outputs."""
+    P = _dev(poses, torch.float32, "poses")
+    N = int(P.shape[0])
+    bb = _dev(bbox2d, torch.float32, "bbox2d")
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    dev = P.device
+    outs = {}
+
+    def alloc(name, shape, dt):
+        if name in want:
+            outs[name] = torch.empty(shape, dtype=dt, device=dev)
+            return outs[name]
+        return None
+
+    if A_out is not None:
+        A = A_out
+        outs["A"] = A
+    else:
+        A = alloc("A", (N, 6, oh, ow), torch.float16 if out_f16 else torch.float32)
+    color = alloc("color", (N, oh, ow, 3), torch.float32)
+    depth = alloc("depth", (N, oh, ow), torch.float32)
+    xyz = alloc("xyz", (N, oh, ow, 3), torch.float32)
+    normal = alloc("normal", (N, oh, ow, 3), torch.float32)
+    zbuf = alloc("zbuf", (N, oh, ow), torch.int32)  # u32 payload, viewed as int32 by torch
+    tri = alloc("tri_id", (N, oh, ow), torch.int32)
+    L = _lib.lib()
+    ws = _workspace(L.fp_workspace_bytes(N, mesh.V, mesh.T, oh, ow), dev)
+    K9 = _hostK32(K)
+    flags = (FLAG_NORMALIZE_XYZ if normalize_xyz else 0) | (FLAG_OUT_F16 if (A is not None and A.dtype == torch.float16) else 0)
+    st = L.fp_render_crops(mesh.handle, _ptr(P), _ptr(bb), K9.ctypes.data_as(C.c_void_p), int(H), int(W), N, oh, ow,
+                           w_ambient, w_diffuse, float(np.float32(mesh_diameter)), xyz_thr, flags, _ptr(A), _ptr(color),
+                           _ptr(depth), _ptr(xyz), _ptr(normal), _ptr(zbuf), _ptr(tri), _ptr(ws),
+                           0 if ws is None else ws.numel(), _stream())
+    _lib.check(st, "fp_render_crops")
+    return outs
+
+
+def warp_crops(rgb, xyz_map, depth, tf_to_crops, K, poses, mesh_diameter, mode, normalize_xyz=True, out_f16=False,
+               out_hw=(160, 160), B_out=None):
+    rgbf = _dev(rgb, torch.float32, "rgb")
+    H, W = int(rgbf.shape[0]), int(rgbf.shape[1])
+    xm = _dev(xyz_map, torch.float32, "xyz_map")
+    dp = _dev(depth, torch.float32, "depth")
+    tf = _dev(tf_to_crops, torch.float32, "tf_to_crops")
+    P = _dev(poses, torch.float32, "poses")
+    N = int(P.shape[0])
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    B = B_out if B_out is not None else torch.empty((N, 6, oh, ow), dtype=torch.float16 if out_f16 else torch.float32,
+                                                    device=P.device)
+    flags = (FLAG_NORMALIZE_XYZ if normalize_xyz else 0) | (FLAG_OUT_F16 if B.dtype == torch.float16 else 0)
+    K9 = _hostK32(K)
+    st = _lib.lib().fp_warp_crops(_ptr(rgbf), _ptr(xm), _ptr(dp), _ptr(tf), K9.ctypes.data_as(C.c_void_p), _ptr(P),
+                                  float(np.float32(mesh_diameter)), flags, int(mode), H, W, N, oh, ow, _ptr(B), _stream())
+    _lib.check(st, "fp_warp_crops")
+    return B
+
+
+def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, trans_normalizer=(1.0, 1.0, 1.0),
+                rot_normalizer=1.0, mesh_diameter=1.0, out=None):
+    tr = _dev(trans, torch.float32, "trans")
+    ro = _dev(rot, torch.float32, "rot")
+    P = _dev(poses, torch.float32, "poses")
+    N = int(P.shape[0])
+    if rot_rep == "axis_angle":
+        rr = ROT_AXIS_ANGLE
+    elif rot_rep == "6d":
+        rr = ROT_6D
+    else:
+        raise RuntimeError(f"unknown rot_rep {rot_rep}")
+    tn = np.ascontiguousarray(np.broadcast_to(np.asarray(trans_normalizer, dtype=np.float32).reshape(-1), (3,)))
+    O = out if out is not None else torch.empty_like(P)
+    st = _lib.lib().fp_pose_update(_ptr(tr), _ptr(ro), _ptr(P), rr, int(bool(normalize_xyz)),
+                                   tn.ctypes.data_as(C.c_void_p), float(rot_normalizer), float(np.float32(mesh_diameter)),
+                                   N, _ptr(O), _stream())
+    _lib.check(st, "fp_pose_update")
+    return O
+
+
+def conv7x7s2_bn_relu(x, w_flat, scale, shift, channels_last=False):
+    """x (B,6,H,W) f16 NCHW -> (B,64,H/2,W/2) f16 (logical NCHW; channels_last memory format if asked)."""
+    x = _dev(x, torch.float16, "x")
+    w = _dev(w_flat, torch.float16, "w")
+    sc = _dev(scale, torch.float32, "scale")
+    sh = _dev(shift, torch.float32, "shift")
+    Bn, Cin, H, W = x.shape
+    if Cin != 6:
+        raise _lib.FpAmdError("conv7x7s2_bn_relu: C_in must be 6")
+    if channels_last:
+        y = torch.empty((Bn, 64, H // 2, W // 2), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    else:
+        y = torch.empty((Bn, 64, H // 2, W // 2), dtype=torch.float16, device=x.device)
+    st = _lib.lib().fp_conv7x7s2_bn_relu_fwd(_ptr(x), _ptr(w), _ptr(sc), _ptr(sh), _ptr(y), int(Bn), int(H), int(W),
+                                             int(bool(channels_last)), _stream())
+    _lib.check(st, "fp_conv7x7s2_bn_relu_fwd")
+    return y
+
+
+def linear_f16(x, w, bias=None, relu=False):
+    """y = x @ w.T + bias ; x (...,K) f16, w (Nout,K) f16, bias (Nout) f32."""
+    x2 = _dev(x.reshape(-1, x.shape[-1]), torch.float16, "x")
+    w = _dev(w, torch.float16, "w")
+    b = _dev(bias, torch.float32, "bias")
+    M, K = x2.shape
+    Nout = int(w.shape[0])
+    y = torch.empty((M, Nout), dtype=torch.float16, device=x.device)
+    st = _lib.lib().fp_linear_f16_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), int(M), int(K), Nout, int(bool(relu)), _stream())
+    _lib.check(st, "fp_linear_f16_fwd")
+    return y.reshape(*x.shape[:-1], Nout)
+
+
+def cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs):
+    """Host op (init-time): returns indices of the kept poses (mycpp.cluster_poses semantics)."""
+    P = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 16))
+    S = np.ascontiguousarray(np.asarray(symmetry_tfs, dtype=np.float32).reshape(-1, 16))
+    keep = np.empty(P.shape[0], np.int32)
+    n = _lib.lib().fp_cluster_poses(float(angle_diff), float(dist_diff), P.ctypes.data_as(C.c_void_p), P.shape[0],
+                                    S.ctypes.data_as(C.c_void_p), S.shape[0], keep.ctypes.data_as(C.c_void_p))
+    return keep[:n].copy()

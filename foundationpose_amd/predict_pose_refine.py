@@ -1,0 +1,163 @@
+"""PoseRefinePredictor -- drop-in for learning/training/predict_pose_refine.py:93-295.
+
+``predict`` keeps the reference signature and return types.  Per iteration the reference launches ~60 kernels
+(crop tf, nvdiffrast x7, kornia warps, dataset transform, concat, pose update); here it is four launches of
+libfp_amd.so (fp_crop_windows, fp_render_crops, fp_warp_crops, fp_pose_update) around the network plan, with
+no host round trip inside the loop.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .Utils import get_mesh_handle, make_mesh_tensors
+from .engine import RefinePlan
+from .h5_dataset import PoseRefinePairH5Dataset
+from .pose_dataset import BatchPoseData
+from .refine_network import RefineNet
+from .weights import DEFAULT_REFINE_CFG
+
+_REFINE_DEFAULTS = dict(use_normal=False, use_mask=False, use_BN=False, c_in=4, crop_ratio=1.2, n_view=1,
+                        trans_rep="tracknet", rot_rep="axis_angle", zfar=3, normalize_xyz=False, normal_uint8=False)
+
+
+class _Cfg(dict):
+    """dict with attribute access (stands in for OmegaConf's DictConfig, which is not available here)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def load_run(run_name, weights_root=None):
+    """weights/<run_name>/{config.yml, model_best.pth} as in predict_pose_refine.py:97-141."""
+    import yaml
+    root = weights_root or os.environ.get("FOUNDATIONPOSE_WEIGHTS") or os.path.join(
+        os.path.dirname(os.path.abspath(__file__)), "..", "weights")
+    cfg_path = os.path.join(root, run_name, "config.yml")
+    ckpt_path = os.path.join(root, run_name, "model_best.pth")
+    if not (os.path.exists(cfg_path) and os.path.exists(ckpt_path)):
+        raise FileNotFoundError(
+            f"pretrained run '{run_name}' not found under {root}; pass cfg= and state_dict= explicitly "
+            f"(e.g. foundationpose_amd.weights.random_state_dict) or set FOUNDATIONPOSE_WEIGHTS")
+    with open(cfg_path) as f:
+        cfg = yaml.safe_load(f)
+    ckpt = torch.load(ckpt_path, map_location="cpu")
+    if "model" in ckpt:
+        ckpt = ckpt["model"]
+    return cfg, ckpt, ckpt_path
+
+
+def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_ratio, xyz_map, normal_map=None,
+                         mesh_diameter=None, cfg=None, glctx=None, mesh_tensors=None, dataset=None, AB=None):
+    """Reference: predict_pose_refine.py:26-89.  Returns a BatchPoseData whose rgbAs/xyz_mapAs/rgbBs/xyz_mapBs are
+    views into one (2N,6,h,w) network-input buffer (``batch.AB``): A = rendered hypothesis, B = observed crop."""
+    H, W = depth.shape[:2]
+    handle = get_mesh_handle(mesh_tensors)
+    poseA = torch.as_tensor(ob_in_cams, dtype=torch.float, device=handle.device).reshape(-1, 4, 4).contiguous()
+    N = poseA.shape[0]
+    oh, ow = int(cfg["input_resize"][0]), int(cfg["input_resize"][1])
+    tf_to_crops, bbox2d = ops.crop_windows(poseA, K, mesh_diameter, crop_ratio, (render_size[1], render_size[0]))
+    if N == 2:
+        # reference broadcasting quirk: with exactly two poses transform_pts pairs pose i with
+        # corner i, so both hypotheses are rendered with [umin_0, vmin_0, umax_1, vmax_1]
+        bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
+    if AB is None:
+        AB = torch.empty((2 * N, 6, oh, ow), dtype=torch.float32, device=handle.device)
+    normalize = bool(cfg["normalize_xyz"])
+    for b in range(0, N, 4096):
+        e = min(N, b + 4096)
+        ops.render_crops(handle, poseA[b:e], bbox2d[b:e], K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
+                         xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[b:e])
+        ops.warp_crops(rgb, xyz_map, None, tf_to_crops[b:e], K, poseA[b:e], mesh_diameter, ops.MODE_REFINE,
+                       normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[N + b:N + e])
+    Ks = torch.as_tensor(np.asarray(K, dtype=np.float64), device=handle.device, dtype=torch.float).reshape(1, 3, 3)
+    mesh_diameters = torch.ones((N,), dtype=torch.float, device=handle.device) * float(mesh_diameter)
+    batch = BatchPoseData(rgbAs=AB[:N, :3], rgbBs=AB[N:, :3], xyz_mapAs=AB[:N, 3:], xyz_mapBs=AB[N:, 3:], poseA=poseA,
+                          tf_to_crops=tf_to_crops, Ks=Ks, mesh_diameters=mesh_diameters)
+    batch.AB = AB
+    batch.bbox2d = bbox2d
+    if dataset is not None:
+        batch = dataset.transform_batch(batch=batch, H_ori=H, W_ori=W, bound=1)
+    return batch
+
+
+class PoseRefinePredictor:
+    run_name = "2023-10-28-18-33-37"
+
+    def __init__(self, cfg=None, state_dict=None, weights_root=None, device="cuda", precision="fp16",
+                 channels_last=True, use_hip_gemm=True):
+        self.amp = precision != "fp32"
+        if cfg is None or state_dict is None:
+            cfg, state_dict, ckpt_dir = load_run(self.run_name, weights_root)
+        else:
+            ckpt_dir = None
+        self.cfg = _Cfg(cfg)
+        self.cfg["ckpt_dir"] = ckpt_dir
+        self.cfg["enable_amp"] = True
+        for k, v in _REFINE_DEFAULTS.items():  # backward-compat defaults, predict_pose_refine.py:107-130
+            if k not in self.cfg or (k == "crop_ratio" and self.cfg[k] is None):
+                self.cfg[k] = v
+        if isinstance(self.cfg["zfar"], str) and "inf" in self.cfg["zfar"].lower():
+            self.cfg["zfar"] = np.inf
+        for k in ("input_resize", "trans_normalizer", "rot_normalizer"):
+            if k not in self.cfg:
+                raise KeyError(f"refiner cfg lacks required key '{k}'")
+        if self.cfg["trans_rep"] != "tracknet":
+            raise NotImplementedError("only trans_rep='tracknet' (the released configuration) is implemented")
+        if self.cfg["use_normal"]:
+            raise NotImplementedError("use_normal=True is not supported (the released models use c_in=6)")
+        if self.cfg["c_in"] != 6:
+            raise NotImplementedError("c_in must be 6 (rgb + xyz)")
+        self.dataset = PoseRefinePairH5Dataset(cfg=self.cfg, h5_file="", mode="test")
+        self.device = torch.device(device)
+        self.precision = precision
+        self._plan_opts = dict(precision=precision, channels_last=channels_last, use_hip=use_hip_gemm)
+        self.model = RefineNet(cfg=self.cfg, c_in=self.cfg["c_in"])
+        self.model.load_state_dict(state_dict)
+        self.model.to(self.device).eval()
+        self._plan = None
+        self.last_trans_update = None
+        self.last_rot_update = None
+
+    def plan(self):
+        dev = next(self.model.parameters()).device
+        if self._plan is None or self._plan_dev != dev:
+            self._plan = RefinePlan(self.model, dev, **self._plan_opts)
+            self._plan_dev = dev
+        return self._plan
+
+    @torch.inference_mode()
+    def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None,
+                mesh_tensors=None, glctx=None, mesh_diameter=None, iteration=5):
+        """@rgb (H,W,3) uint8/float np or tensor; @ob_in_cams (N,4,4) np or tensor.  -> ((N,4,4) f32 device tensor, vis)"""
+        plan = self.plan()
+        dev = self._plan_dev
+        if mesh_tensors is None:
+            mesh_tensors = make_mesh_tensors(mesh, device=dev)
+        B_in_cams = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous()
+        N = B_in_cams.shape[0]
+        rgb_t = torch.as_tensor(rgb, device=dev).to(torch.float).contiguous()
+        depth_t = torch.as_tensor(depth, device=dev, dtype=torch.float).contiguous()
+        xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
+        oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
+        tn = self.cfg["trans_normalizer"]
+        tn = [float(tn)] * 3 if isinstance(tn, (int, float)) else [float(v) for v in tn]
+        AB = torch.empty((2 * N, 6, oh, ow), dtype=plan.dtype, device=dev)
+        trans = rot = None
+        for _ in range(iteration):
+            batch = make_crop_data_batch(self.cfg["input_resize"], B_in_cams, mesh, rgb_t, depth_t, K,
+                                         crop_ratio=self.cfg["crop_ratio"], xyz_map=xyz_t, cfg=self.cfg, glctx=glctx,
+                                         mesh_tensors=mesh_tensors, dataset=self.dataset, mesh_diameter=mesh_diameter,
+                                         AB=AB)
+            out = plan(batch.AB)
+            trans, rot = out["trans"].contiguous(), out["rot"].contiguous()
+            B_in_cams = ops.pose_update(trans, rot, batch.poseA, rot_rep=self.cfg["rot_rep"],
+                                        normalize_xyz=bool(self.cfg["normalize_xyz"]), trans_normalizer=tn,
+                                        rot_normalizer=float(self.cfg["rot_normalizer"]),
+                                        mesh_diameter=float(mesh_diameter))
+        self.last_trans_update = trans
+        self.last_rot_update = rot
+        if get_vis:
+            logging.info("get_vis canvases are not implemented (debug-only path, SURVEY 8(f) rank 4)")
+        return B_in_cams, None

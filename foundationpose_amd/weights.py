@@ -1,0 +1,81 @@
+"""Deterministic stand-in checkpoints.  The reference's weights/ directory is not shipped,
+so tests / bench / golden vectors use a procedurally generated state_dict: every tensor is drawn from a
+CPU generator seeded by (seed, crc32(key)), which is stable across processes, machines and torch builds.
+Key names and shapes are those of the reference modules (SURVEY.md 8(c) 'State-dict compatibility')."""
+import math
+import zlib
+
+import torch
+
+DEFAULT_REFINE_CFG = dict(use_BN=True, c_in=6, input_resize=[160, 160], crop_ratio=1.2, normalize_xyz=True,
+                          rot_rep="axis_angle", trans_rep="tracknet", trans_normalizer=[0.019999999552965164, 0.019999999552965164, 0.05000000074505806],
+                          rot_normalizer=0.3490658503988659, use_normal=False, use_mask=False, n_view=1,
+                          zfar=float("inf"), normal_uint8=False)
+DEFAULT_SCORE_CFG = dict(use_BN=True, c_in=6, input_resize=[160, 160], crop_ratio=1.1, normalize_xyz=True,
+                         use_normal=False, zfar=float("inf"))
+
+
+def _gen(seed, key):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) % (2 ** 31 - 1))
+    return g
+
+
+def positional_table(max_len=400, d_model=512):
+    """network_modules.py:115-130 PositionalEmbedding buffer."""
+    pe = torch.zeros(max_len, d_model, dtype=torch.float32)
+    position = torch.arange(0, max_len).float().unsqueeze(1)
+    div_term = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()[None]
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0)
+
+
+def fill_state_dict(template, seed=0, head_gain=1.0):
+    """template: {key: tensor} giving names/shapes/dtypes; returns a new dict with seeded values."""
+    out = {}
+    for k, t in template.items():
+        g = _gen(seed, k)
+        shape = tuple(t.shape)
+        if k.endswith("num_batches_tracked"):
+            v = torch.zeros(shape, dtype=t.dtype)
+        elif k.endswith("pos_embed.pe"):
+            v = positional_table(shape[1], shape[2])
+        elif k.endswith("running_mean"):
+            v = torch.randn(shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            v = torch.rand(shape, generator=g) + 0.5
+        elif "norm" in k.split(".")[-2] or ".bn" in k or k.split(".")[-2] == "1" and len(shape) == 1 and "net" in k:
+            # BatchNorm / LayerNorm affine parameters
+            v = (torch.rand(shape, generator=g) + 0.5) if k.endswith("weight") else torch.randn(shape, generator=g) * 0.1
+        elif len(shape) >= 2:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            v = torch.randn(shape, generator=g) * math.sqrt(1.0 / fan_in)
+            if ("head.1." in k) or k.startswith("linear."):
+                v = v * head_gain
+        else:
+            v = torch.randn(shape, generator=g) * 0.05
+        out[k] = v.to(t.dtype) if t.dtype.is_floating_point else v.to(t.dtype)
+    return out
+
+
+def random_state_dict(kind, cfg=None, seed=0):
+    """kind in {'refine','score'} -> seeded state_dict for RefineNet / ScoreNetMultiPair."""
+    from .refine_network import RefineNet
+    from .score_network import ScoreNetMultiPair
+    if kind == "refine":
+        cfg = dict(DEFAULT_REFINE_CFG, **(cfg or {}))
+        with torch.device("meta"):
+            net = RefineNet(cfg=cfg, c_in=cfg["c_in"])
+        gain = 8.0
+    elif kind == "score":
+        cfg = dict(DEFAULT_SCORE_CFG, **(cfg or {}))
+        with torch.device("meta"):
+            net = ScoreNetMultiPair(cfg=cfg, c_in=cfg["c_in"])
+        gain = 8.0
+    else:
+        raise ValueError(kind)
+    template = {k: v for k, v in net.state_dict().items()}
+    return fill_state_dict(template, seed=seed, head_gain=gain)

@@ -1,0 +1,136 @@
+/*
+ * fp_amd.h -- C ABI of the MI355X-native render-and-compare hot path (libfp_amd.so).
+ *
+ * The reference (NVlabs/FoundationPose) has no FFI boundary for this path: it is plain
+ * Python calling nvdiffrast / kornia / warp / torch.  This header is
+ * therefore the boundary *underneath* the preserved Python API; every entry point cites the
+ * reference lines it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / STL types.
+ *   - return 0 on success, a negative fp_status otherwise; fp_last_error() gives the message
+ *     (thread-local).
+ *   - pointers marked [dev] are device (HBM) pointers owned by the caller; [host] are host
+ *     pointers read before the call returns.  No entry point allocates, frees or synchronises;
+ *     all work is enqueued on `stream` (a hipStream_t), so sequences are hipGraph-capturable.
+ *   - images are row-major; poses are row-major 4x4 float32 `ob_in_cam` (OpenCV camera).
+ */
+#ifndef FP_AMD_H
+#define FP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  FP_OK = 0,
+  FP_ERR_INVALID_ARG = -1,
+  FP_ERR_WORKSPACE = -2,
+  FP_ERR_LAUNCH = -3,
+  FP_ERR_UNSUPPORTED = -4
+} fp_status;
+
+/* flags for fp_render_crops / fp_warp_crops */
+#define FP_FLAG_NORMALIZE_XYZ 1 /* cfg['normalize_xyz'] (h5_dataset.py:95-101,151-156) */
+#define FP_FLAG_OUT_F16 2       /* write the network tensor (A / B) as fp16 instead of fp32 */
+
+/* fp_warp_crops mode */
+#define FP_MODE_REFINE 0 /* predict_pose_refine.py:63,72 + PairH5Dataset.transform_batch */
+#define FP_MODE_SCORE 1  /* predict_score.py:89-90 + TripletH5Dataset.transform_depth_to_xyzmap */
+
+/* fp_pose_update rot_rep */
+#define FP_ROT_AXIS_ANGLE 0
+#define FP_ROT_6D 1
+
+/* integer z-buffer definition; shared with oracle/fp_oracle.c */
+#define FP_SUBPIXEL_BITS 4
+#define FP_ZBUF_STEPS_PER_METRE 1048576 /* 2^20 */
+#define FP_ZBUF_EMPTY 0xFFFFFFFFu
+
+typedef struct fp_mesh fp_mesh; /* opaque: device pointers + sizes of one object's mesh tensors */
+
+const char* fp_last_error(void);
+int fp_version(void);
+
+/* Utils.py:104-130 make_mesh_tensors: records caller-owned device tensors.
+ * pos/nrm (V,3) f32, faces (T,3) i32; either {tex (Ht,Wt,3) f32 in [0,1], uv (V',2) f32 with v already
+ * flipped (Utils.py:117), uv_idx (T,3) i32 or NULL => faces} or {vcol (V,3) f32 in [0,1]}. */
+int fp_mesh_create(const float* pos /*dev*/, const float* nrm /*dev*/, const int32_t* faces /*dev*/,
+                   const float* uv /*dev|NULL*/, const int32_t* uv_idx /*dev|NULL*/,
+                   const float* tex /*dev|NULL*/, const float* vcol /*dev|NULL*/, int V, int T, int Ht,
+                   int Wt, fp_mesh** out);
+void fp_mesh_destroy(fp_mesh* mesh);
+
+/* Utils.py:359-395 erode_depth (+ kernel) */
+int fp_depth_erode(const float* depth /*dev H,W*/, float* out /*dev*/, int H, int W, int radius,
+                   float depth_diff_thres, float ratio_thres, float zfar, void* stream);
+/* Utils.py:304-356 bilateral_filter_depth (+ kernel) */
+int fp_depth_bilateral(const float* depth /*dev*/, float* out /*dev*/, int H, int W, int radius,
+                       float zfar, float sigmaD, float sigmaR, void* stream);
+/* Utils.py:399-417 depth2xyzmap (f64_internal=1, numpy promotion) / :420-438 depth2xyzmap_batch (0) */
+int fp_depth_to_xyz(const float* depth /*dev H,W*/, const double* K /*host 9*/, float zfar,
+                    int f64_internal, float* xyz /*dev H,W,3*/, int H, int W, void* stream);
+
+/* Utils.py:577-621 compute_crop_window_tf_batch(method='box_3d') and the bbox of
+ * predict_pose_refine.py:44-45 / predict_score.py:74-75 (closed-form inverse). */
+int fp_crop_windows(const float* poses /*dev N,16*/, const double* K /*host 9*/, double mesh_diameter,
+                    double crop_ratio, int out_w, int out_h, int N, float* tf_to_crops /*dev N,9*/,
+                    float* bbox2d /*dev N,4*/, void* stream);
+
+/* bytes of scratch fp_render_crops needs for (N hypotheses, V vertices, oh x ow crops) */
+size_t fp_workspace_bytes(int N, int V, int T, int oh, int ow);
+
+/* Utils.py:133-219 nvdiffrast_render (dr.rasterize + interpolate x5 + texture + Lambert shading + flips)
+ * fused with predict_pose_refine.py:54-56 (*255), h5_dataset.py:79-114 (/255, xyz - t, 1/radius, masks)
+ * and the channel concat of predict_pose_refine.py:187 (A = [rgb, xyz]).
+ * bbox2d NULL => full frame (needs oh=H, ow=W).  Any output may be NULL.
+ *   A      (N,6,oh,ow) f32|f16 ; color (N,oh,ow,3) ; depth (N,oh,ow) ; xyz (N,oh,ow,3) ; normal (N,oh,ow,3)
+ *   zbuf   (N,oh,ow) u32 fixed-point camera depth of the winner, FP_ZBUF_EMPTY if none ; tri_id i32, -1 if none */
+int fp_render_crops(const fp_mesh* mesh, const float* poses /*dev N,16*/, const float* bbox2d /*dev N,4|NULL*/,
+                    const float* K9 /*host 9 f32*/, int H, int W, int N, int oh, int ow, float w_ambient,
+                    float w_diffuse, float mesh_diameter, float xyz_thr, int flags, void* A /*dev*/,
+                    float* color /*dev*/, float* depth /*dev*/, float* xyz /*dev*/, float* normal /*dev*/,
+                    uint32_t* zbuf /*dev*/, int32_t* tri_id /*dev*/, void* workspace /*dev*/,
+                    size_t workspace_bytes, void* stream);
+
+/* kornia warp_perspective call sites predict_pose_refine.py:63,72 / predict_score.py:89,90 fused with
+ * h5_dataset.py:79-114 (refine) or :137-170 (score: depth crop -> frame -> back-projection -> crop) and
+ * the concat of predict_pose_refine.py:188 (B = [rgb, xyz]).
+ * rgb (H,W,3) f32 in 0..255; xyz_map (H,W,3) f32 (REFINE); depth (H,W) f32 (SCORE). */
+int fp_warp_crops(const float* rgb /*dev*/, const float* xyz_map /*dev|NULL*/, const float* depth /*dev|NULL*/,
+                  const float* tf_to_crops /*dev N,9*/, const float* K9 /*host 9 f32*/,
+                  const float* poses /*dev N,16*/, float mesh_diameter, int flags, int mode, int H, int W,
+                  int N, int oh, int ow, void* B /*dev N,6,oh,ow*/, void* stream);
+
+/* predict_pose_refine.py:195-234 + Utils.py:848-855 + pytorch3d so3_exp_map / rotation_6d_to_matrix */
+int fp_pose_update(const float* trans /*dev N,3*/, const float* rot /*dev N,3|6*/,
+                   const float* poses_in /*dev N,16*/, int rot_rep, int normalize_xyz,
+                   const float* trans_normalizer /*host 3*/, float rot_normalizer, float mesh_diameter, int N,
+                   float* poses_out /*dev N,16*/, void* stream);
+
+/* refine_network.py:38 / score_network.py:37 first ConvBNReLU (7x7, stride 2, pad 3, C_in -> 64) with the
+ * eval-mode BatchNorm folded into (scale, shift) and ReLU fused: the "patch-embed conv" as an MFMA implicit GEMM.
+ * x (B,6,160,160) f16 NCHW ; w (64, 6*7*7) f16 row-major (PyTorch conv weight flattened) ;
+ * scale/shift (64) f32 : y = relu(conv(x,w) * scale + shift) ; y (B,64,80,80) f16, NCHW or NHWC (channels_last). */
+int fp_conv7x7s2_bn_relu_fwd(const void* x /*dev*/, const void* w /*dev*/, const float* scale /*dev*/,
+                             const float* shift /*dev*/, void* y /*dev*/, int B, int Hin, int Win,
+                             int channels_last_out, void* stream);
+
+/* nn.MultiheadAttention / nn.TransformerEncoderLayer in_proj (refine_network.py:56-70, score_network.py:52-53):
+ * y[M,Nout] = x[M,K] @ w[Nout,K]^T + bias, fp16 in / fp32 accumulate / fp16 out (the QKV projection,
+ * K=512, Nout=1536; also used for the other 512-wide projections). */
+int fp_linear_f16_fwd(const void* x /*dev M,K f16*/, const void* w /*dev Nout,K f16*/,
+                      const float* bias /*dev Nout f32|NULL*/, void* y /*dev M,Nout f16*/, int M, int K, int Nout,
+                      int relu, void* stream);
+
+/* mycpp/src/app/pybind_api.cpp:24-68 cluster_poses (host, init-time). Returns #kept, indices in keep_idx. */
+int fp_cluster_poses(float angle_diff_deg, float dist_diff, const float* poses /*host N,16*/, int N,
+                     const float* symmetry_tfs /*host S,16*/, int S, int* keep_idx /*host N*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FP_AMD_H */

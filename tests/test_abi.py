@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads and exports exactly what include/fp_amd.h declares."""
+import os
+import re
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "fp_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from foundationpose_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    lib = _lib.lib()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in fp_amd.h but not exported by libfp_amd.so"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in foundationpose_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.fp_version() >= 100
+
+
+def test_argument_errors_are_reported_without_gpu():
+    import ctypes as C
+    from foundationpose_amd import _lib
+    lib = _lib.lib()
+    h = C.c_void_p()
+    st = lib.fp_mesh_create(None, None, None, None, None, None, None, 0, 0, 0, 0, C.byref(h))
+    assert st == -1 and b"fp_mesh_create" in lib.fp_last_error()
+    assert lib.fp_linear_f16_fwd(C.c_void_p(8), C.c_void_p(8), None, C.c_void_p(8), 4, 33, 128, 0, None) == -1
+    assert b"multiple" in lib.fp_last_error()
+    assert lib.fp_workspace_bytes(252, 2501, 4900, 160, 160) == 0          # vertex cache lives in LDS
+    assert lib.fp_workspace_bytes(4, 100000, 200000, 160, 160) == 4 * 100000 * 8
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "foundationpose_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), fn
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from foundationpose_amd import _lib, ops
+    with pytest.raises(_lib.FpAmdError):
+        ops.erode_depth(torch.zeros(4, 4))
+
+
+def test_cluster_poses_host_op(scene):
+    import numpy as np
+    from foundationpose_amd import ops
+    from foundationpose_amd.Utils import symmetry_tfs_from_info
+    from oracle import ops as oo
+    grid = scene["poses"].copy()
+    keep = ops.cluster_poses(30, 99999, grid, np.eye(4)[None])
+    assert len(keep) == 252  # identity symmetry: all 252 survive 30 deg clustering
+    sym = symmetry_tfs_from_info({"symmetries_continuous": [{"axis": [0, 0, 1], "offset": [0, 0, 0]}]})
+    assert sym.shape == (73, 4, 4)
+    k2 = ops.cluster_poses(30, 99999, grid, sym)
+    k2o = oo.cluster_poses(30, 99999, grid, sym)
+    assert len(k2) < 252 and np.array_equal(k2, k2o)
+    assert np.array_equal(keep, oo.cluster_poses(30, 99999, grid, np.eye(4)[None]))
