@@ -319,7 +319,7 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_render(
     if (out.A) {
       float a[6];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a[c] = (col[c] * 255.0f) / 255.0f;
+      for (int c = 0; c < 3; ++c) a[c] = (col[c] * 255.0f) * (1.0f / 255.0f);  // torch GPU `/255.0` = mul by f32 reciprocal
       const bool invalid = pt[2] < xyz_thr;
       const float d[3] = {pt[0] - t0, pt[1] - t1, pt[2] - t2};
 #pragma unroll

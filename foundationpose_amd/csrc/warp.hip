@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_warp(const float* __restrict__ rgb, con
       if (vx1 && vy0) acc += rgb[((size_t)y0 * W + x1) * 3 + c] * wne;
       if (vx0 && vy1) acc += rgb[((size_t)y1 * W + x0) * 3 + c] * wsw;
       if (vx1 && vy1) acc += rgb[((size_t)y1 * W + x1) * 3 + c] * wse;
-      a[c] = acc / 255.0f;
+      a[c] = acc * (1.0f / 255.0f);  // torch GPU `/255.0` = mul by f32 reciprocal
     }
   }
   // ---- xyz, nearest

@@ -252,3 +252,53 @@ def cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs):
     n = _lib.lib().fp_cluster_poses(float(angle_diff), float(dist_diff), P.ctypes.data_as(C.c_void_p), P.shape[0],
                                     S.ctypes.data_as(C.c_void_p), S.shape[0], keep.ctypes.data_as(C.c_void_p))
     return keep[:n].copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# optional per-entry-point timing with HIP events on the launch stream (used by bench.py for the roofline numbers)
+class KernelTimers:
+    """with KernelTimers() as t: ...; t.summary() -> {name: (calls, avg_ms)} measured with events on the current stream."""
+
+    active = None
+
+    def __init__(self):
+        self.records = {}
+
+    def __enter__(self):
+        KernelTimers.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimers.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), float(sum(ms) / max(1, len(ms))))
+        return out
+
+
+def _timed(name, fn):
+    def wrapper(*a, **k):
+        t = KernelTimers.active
+        if t is None:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        t.records.setdefault(name, []).append((e0, e1))
+        return r
+    wrapper.__name__ = fn.__name__
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
+render_crops = _timed("fp_render_crops", render_crops)
+warp_crops = _timed("fp_warp_crops", warp_crops)
+crop_windows = _timed("fp_crop_windows", crop_windows)
+pose_update = _timed("fp_pose_update", pose_update)
+conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu)
+linear_f16 = _timed("fp_linear_f16_fwd", linear_f16)

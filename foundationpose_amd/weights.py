@@ -78,4 +78,33 @@ def random_state_dict(kind, cfg=None, seed=0):
     else:
         raise ValueError(kind)
     template = {k: v for k, v in net.state_dict().items()}
-    return fill_state_dict(template, seed=seed, head_gain=gain)
+    calibrated = seed == 0 and cfg.get("use_BN", False) and cfg.get("rot_rep", "axis_angle") == "axis_angle"
+    sd = fill_state_dict(template, seed=seed, head_gain=1.0 if calibrated else gain)
+    if calibrated:
+        sd.update(_calibration_overlay(kind, sd))
+    return sd
+
+
+_CALIB = None
+
+
+def _calibration_overlay(kind, sd):
+    """seed-0 checkpoints: BatchNorm statistics and head scales measured on crops of the synthetic scene
+    (tests/golden/calibrate_standin.py) so that the stand-in networks are input-sensitive and well scaled."""
+    global _CALIB
+    import os
+    import numpy as np
+    if _CALIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "standin_calib.npz")
+        _CALIB = dict(np.load(path)) if os.path.exists(path) else {}
+    out = {}
+    if kind == "score" and "score/att_cross.qk_gain" in _CALIB:
+        W = sd["att_cross.in_proj_weight"].clone()
+        W[512:1024] = W[:512]
+        W[:1024] *= float(_CALIB["score/att_cross.qk_gain"])
+        out["att_cross.in_proj_weight"] = W
+    for k, v in _CALIB.items():
+        pre, key = k.split("/", 1)
+        if pre == kind and key in sd:
+            out[key] = torch.from_numpy(v).to(sd[key].dtype).reshape(sd[key].shape)
+    return out

@@ -281,6 +281,7 @@ void fpo_render_crops(const float* pos, const float* nrm, const int* faces, cons
   const size_t npx = (size_t)oh * ow;
   const int normalize = flags & FPO_FLAG_NORMALIZE_XYZ;
   const float inv_r = 1.0f / (mesh_diameter * 0.5f);
+  const float inv255 = 1.0f / 255.0f;
 #pragma omp parallel
   {
     fpo_vtx* vt = (fpo_vtx*)malloc(sizeof(fpo_vtx) * (size_t)V);
@@ -424,7 +425,8 @@ void fpo_render_crops(const float* pos, const float* nrm, const int* faces, cons
           if (normal) { normal[o * 3] = nm[0]; normal[o * 3 + 1] = nm[1]; normal[o * 3 + 2] = nm[2]; }
           if (A) {
             float* a = A + (size_t)n * 6 * npx + p;
-            for (int c = 0; c < 3; ++c) a[(size_t)c * npx] = (col[c] * 255.0f) / 255.0f;
+            /* torch's GPU `tensor / 255.0` multiplies by the f32 reciprocal (BinaryDivTrueKernel scalar fast path) */
+            for (int c = 0; c < 3; ++c) a[(size_t)c * npx] = (col[c] * 255.0f) * inv255;
             int invalid = pt[2] < xyz_thr;
             float d[3] = {pt[0] - t0, pt[1] - t1, pt[2] - t2};
             for (int c = 0; c < 3; ++c) {
@@ -458,6 +460,7 @@ void fpo_warp_crops(const float* rgb /*H,W,3 0..255*/, const float* xyz_map /*H,
   const float cW = (float)W / (float)(W - 1), cH = (float)H / (float)(H - 1);
   const float cSw = (float)ow / (float)(ow - 1), cSh = (float)oh / (float)(oh - 1);
   const float thr = (mode == FPO_MODE_SCORE) ? 0.1f : 0.001f;
+  const float inv255 = 1.0f / 255.0f;
 #pragma omp parallel for schedule(dynamic, 1)
   for (int n = 0; n < N; ++n) {
     const float* tf = tf_to_crops + (size_t)n * 9;
@@ -484,7 +487,7 @@ void fpo_warp_crops(const float* rgb /*H,W,3 0..255*/, const float* xyz_map /*H,
           if (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H) acc += rgb[((size_t)y0 * W + x1) * 3 + c] * wne;
           if (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H) acc += rgb[((size_t)y1 * W + x0) * 3 + c] * wsw;
           if (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H) acc += rgb[((size_t)y1 * W + x1) * 3 + c] * wse;
-          b[(size_t)c * npx] = acc / 255.0f;
+          b[(size_t)c * npx] = acc * inv255;
         }
         /* ---- xyz: nearest */
         float pt[3] = {0, 0, 0};

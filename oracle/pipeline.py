@@ -17,7 +17,7 @@ def mesh_tensors_np(mesh):
     image = getattr(material, "image", None) if material is not None else None
     if image is not None and getattr(visual, "uv", None) is not None:
         img = np.asarray(image)[..., :3]
-        t["tex"] = (img.astype(np.float32) / np.float32(255.0))
+        t["tex"] = img.astype(np.float32) * (np.float32(1.0) / np.float32(255.0))  # torch GPU `/255.0` = mul by f32 reciprocal
         uv = np.asarray(visual.uv, dtype=np.float32).copy()
         uv[:, 1] = 1 - uv[:, 1]
         t["uv"] = uv
@@ -25,7 +25,7 @@ def mesh_tensors_np(mesh):
     else:
         vc = visual.vertex_colors if (visual is not None and visual.vertex_colors is not None) else \
             np.tile(np.array([128, 128, 128]).reshape(1, 3), (len(mesh.vertices), 1))
-        t["vertex_color"] = np.asarray(vc)[..., :3].astype(np.float32) / np.float32(255.0)
+        t["vertex_color"] = np.asarray(vc)[..., :3].astype(np.float32) * (np.float32(1.0) / np.float32(255.0))
     return t
 
 

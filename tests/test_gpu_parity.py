@@ -1,0 +1,338 @@
+"""GPU parity tests: every C-ABI entry point of libfp_amd.so against the CPU oracle on the same seeded inputs.
+Integer outputs (z-buffer, triangle ids, erosion) must be bit-exact; floating point within the stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def gmesh(scene, dev):
+    from foundationpose_amd.Utils import make_mesh_tensors
+    return make_mesh_tensors(scene["mesh"], device=dev)
+
+
+@pytest.fixture(scope="module")
+def frame(scene, dev):
+    from oracle import ops as oo
+    from oracle import pipeline as op
+    d = op.preprocess_depth(scene["depth"])
+    xyz = oo.depth2xyzmap(d, scene["K"], f64_internal=True)
+    return dict(depth_f=d, xyz=xyz,
+                rgb_t=torch.as_tensor(scene["rgb"], device=dev).float().contiguous(),
+                depth_t=torch.as_tensor(d, device=dev), xyz_t=torch.as_tensor(xyz, device=dev))
+
+
+def _t(x, dev):
+    return torch.as_tensor(np.ascontiguousarray(x), device=dev)
+
+
+# ------------------------------------------------------------------ frame ops
+def test_erode_bit_exact_and_bilateral(scene, dev):
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    d = scene["depth"].copy()
+    d[:7, :9] = 0; d[100:104, 200:260] = 120.0; d[300, 300] = 0.3
+    e_ref = oo.erode_depth(d)
+    e = ops.erode_depth(_t(d, dev)).cpu().numpy()
+    assert np.array_equal(e, e_ref)
+    b_ref = oo.bilateral_filter_depth(e_ref)
+    b = ops.bilateral_filter_depth(_t(e_ref, dev)).cpu().numpy()
+    np.testing.assert_allclose(b, b_ref, rtol=0, atol=2e-6)  # expf differs by ulps between libm and the GPU
+    assert np.array_equal(b == 0, b_ref == 0)
+
+
+def test_depth_to_xyz_both_variants(scene, dev):
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    d = scene["depth"]
+    for f64 in (True, False):
+        ref = oo.depth2xyzmap(d, scene["K"], zfar=1.0 if not f64 else np.inf, f64_internal=f64)
+        out = ops.depth_to_xyz(_t(d, dev), scene["K"], zfar=1.0 if not f64 else float("inf"), f64_internal=f64).cpu().numpy()
+        assert np.array_equal(out, ref)
+
+
+def test_crop_windows_bit_exact(scene, dev):
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    tf_ref, bb_ref = oo.crop_windows(scene["poses"], scene["K"], scene["diameter"], 1.2, (160, 160))
+    tf, bb = ops.crop_windows(_t(scene["poses"], dev), scene["K"], scene["diameter"], 1.2, (160, 160))
+    assert np.array_equal(tf.cpu().numpy(), tf_ref) and np.array_equal(bb.cpu().numpy(), bb_ref)
+
+
+def test_pose_update(scene, dev):
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    rng = np.random.default_rng(3)
+    P = scene["poses"][:64]
+    tr = rng.normal(size=(64, 3)).astype(np.float32)
+    for rep, rd in (("axis_angle", 3), ("6d", 6)):
+        ro = rng.normal(size=(64, rd)).astype(np.float32)
+        for norm in (True, False):
+            ref = oo.pose_update(tr, ro, P, rep, norm, (0.02, 0.02, 0.05), 0.349, scene["diameter"])
+            out = ops.pose_update(_t(tr, dev), _t(ro, dev), _t(P, dev), rep, norm, (0.02, 0.02, 0.05), 0.349,
+                                  scene["diameter"]).cpu().numpy()
+            np.testing.assert_allclose(out, ref, rtol=0, atol=3e-6)  # tanhf / sinf / cosf ulps
+
+
+# ------------------------------------------------------------------ rasteriser
+@pytest.mark.parametrize("textured", [True, False])
+def test_render_crops_zbuffer_bit_exact(scene, dev, textured):
+    from foundationpose_amd import ops
+    from foundationpose_amd.mesh import make_can_mesh
+    from foundationpose_amd.Utils import make_mesh_tensors
+    from oracle import ops as oo
+    from oracle import pipeline as op
+    mesh = scene["mesh"] if textured else make_can_mesh(textured=False)
+    mnp = op.mesh_tensors_np(mesh)
+    gm = make_mesh_tensors(mesh, device=dev)
+    P = scene["poses"][::7]  # 36 hypotheses across the grid
+    tf, bb = oo.crop_windows(P, scene["K"], scene["diameter"], 1.2, (160, 160))
+    want = ("A", "color", "depth", "xyz", "normal", "zbuf", "tri_id")
+    ref = oo.render_crops(mnp, P, bb, scene["K"], 480, 640, (160, 160), scene["diameter"], 0.001, True, want=want)
+    out = ops.render_crops(gm["_handle"], _t(P, dev), _t(bb, dev), scene["K"], 480, 640, (160, 160), scene["diameter"],
+                           0.001, True, want=want)
+    assert np.array_equal(out["tri_id"].cpu().numpy(), ref["tri_id"]), "triangle ids differ"
+    assert np.array_equal(out["zbuf"].cpu().numpy().view(np.uint32), ref["zbuf"]), "integer z-buffer differs"
+    assert (ref["tri_id"] >= 0).mean() > 0.15
+    for k in ("A", "color", "depth", "xyz", "normal"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=1e-5, err_msg=k)
+
+
+def test_render_crops_fp16_output_and_flags(scene, dev, gmesh):
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    P = scene["poses"][:9]
+    tf, bb = oo.crop_windows(P, scene["K"], scene["diameter"], 1.2, (160, 160))
+    for norm, thr in ((True, 0.1), (False, 0.001)):
+        ref = oo.render_crops(scene["mesh_np"], P, bb, scene["K"], 480, 640, (160, 160), scene["diameter"], thr, norm,
+                              want=("A",))["A"]
+        o16 = ops.render_crops(gmesh["_handle"], _t(P, dev), _t(bb, dev), scene["K"], 480, 640, (160, 160),
+                               scene["diameter"], thr, norm, out_f16=True, want=("A",))["A"]
+        assert o16.dtype == torch.float16
+        o16 = o16.cpu().numpy()
+        r16 = ref.astype(np.float16)  # same f32 values, rounded once to fp16
+        assert (o16 != r16).mean() < 1e-5 and np.abs(o16.astype(np.float32) - r16.astype(np.float32)).max() <= 1e-3
+
+
+def test_render_full_frame_and_ragged_sizes(scene, dev, gmesh):
+    """no bbox (full 480x640 frame, strips of 10 rows) and a non-square crop with a ragged last strip"""
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    T = scene["gt"][None].astype(np.float32)
+    ref = oo.render_crops(scene["mesh_np"], T, None, scene["K"], 480, 640, (480, 640), normalize_xyz=False,
+                          want=("tri_id", "zbuf", "depth"))
+    out = ops.render_crops(gmesh["_handle"], _t(T, dev), None, scene["K"], 480, 640, (480, 640), normalize_xyz=False,
+                           want=("tri_id", "zbuf", "depth"))
+    assert np.array_equal(out["tri_id"].cpu().numpy(), ref["tri_id"])
+    assert np.array_equal(out["zbuf"].cpu().numpy().view(np.uint32), ref["zbuf"])
+    P = scene["poses"][:3]
+    bb = np.array([[180, 60, 500, 350]] * 3, np.float32)
+    ref = oo.render_crops(scene["mesh_np"], P, bb, scene["K"], 480, 640, (104, 88), want=("tri_id", "zbuf"))
+    out = ops.render_crops(gmesh["_handle"], _t(P, dev), _t(bb, dev), scene["K"], 480, 640, (104, 88), want=("tri_id", "zbuf"))
+    assert np.array_equal(out["tri_id"].cpu().numpy(), ref["tri_id"])
+    assert np.array_equal(out["zbuf"].cpu().numpy().view(np.uint32), ref["zbuf"])
+
+
+def test_render_degenerate_inputs(scene, dev, gmesh):
+    """object behind the camera / far outside the crop => empty crops; N=0 is a no-op"""
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    P = scene["poses"][:2].copy()
+    P[0, 2, 3] = -0.5          # behind the camera: every vertex culled
+    bb = np.array([[0, 0, 159, 159], [5000, 5000, 5159, 5159]], np.float32)  # second: window far off the object
+    ref = oo.render_crops(scene["mesh_np"], P, bb, scene["K"], 480, 640, (160, 160), want=("tri_id", "A"))
+    out = ops.render_crops(gmesh["_handle"], _t(P, dev), _t(bb, dev), scene["K"], 480, 640, (160, 160), want=("tri_id", "A"))
+    assert (out["tri_id"].cpu().numpy() == -1).all() and (ref["tri_id"] == -1).all()
+    assert np.array_equal(out["A"].cpu().numpy(), ref["A"])
+    e = ops.render_crops(gmesh["_handle"], torch.empty((0, 4, 4), device=dev), torch.empty((0, 4), device=dev),
+                         scene["K"], 480, 640, (160, 160), want=("A",))
+    assert e["A"].shape[0] == 0
+
+
+def test_render_large_mesh_workspace_path(scene, dev):
+    """V > LDS vertex-cache capacity => vertex pass through the HBM workspace; same bits as the oracle"""
+    from foundationpose_amd import ops
+    from foundationpose_amd.mesh import make_can_mesh
+    from foundationpose_amd.Utils import make_mesh_tensors
+    from oracle import ops as oo
+    from oracle import pipeline as op
+    mesh = make_can_mesh(n_ang=160, n_axial=80, textured=False)  # 12,963 vertices, 25,920 triangles
+    assert ops._lib.lib().fp_workspace_bytes(4, len(mesh.vertices), len(mesh.faces), 160, 160) > 0
+    gm = make_mesh_tensors(mesh, device=dev)
+    P = scene["poses"][:4]
+    tf, bb = oo.crop_windows(P, scene["K"], scene["diameter"], 1.2, (160, 160))
+    ref = oo.render_crops(op.mesh_tensors_np(mesh), P, bb, scene["K"], 480, 640, (160, 160), want=("tri_id", "zbuf", "A"))
+    out = ops.render_crops(gm["_handle"], _t(P, dev), _t(bb, dev), scene["K"], 480, 640, (160, 160), want=("tri_id", "zbuf", "A"))
+    assert np.array_equal(out["tri_id"].cpu().numpy(), ref["tri_id"])
+    assert np.array_equal(out["zbuf"].cpu().numpy().view(np.uint32), ref["zbuf"])
+    np.testing.assert_allclose(out["A"].cpu().numpy(), ref["A"], atol=1e-5)
+
+
+def test_nvdiffrast_render_shim(scene, dev, gmesh):
+    from foundationpose_amd.Utils import nvdiffrast_render
+    from oracle import ops as oo
+    T = scene["gt"][None].astype(np.float32)
+    extra = {}
+    color, depth, normal = nvdiffrast_render(K=scene["K"], H=480, W=640, ob_in_cams=_t(T, dev), mesh_tensors=gmesh,
+                                             use_light=True, extra=extra)
+    ref = oo.render_crops(scene["mesh_np"], T, None, scene["K"], 480, 640, (480, 640), normalize_xyz=False,
+                          want=("color", "depth", "normal", "xyz"))
+    assert color.shape == (1, 480, 640, 3) and depth.shape == (1, 480, 640) and extra["xyz_map"].shape == (1, 480, 640, 3)
+    np.testing.assert_allclose(color.cpu().numpy(), ref["color"], atol=1e-5)
+    np.testing.assert_allclose(depth.cpu().numpy(), ref["depth"], atol=1e-6)
+    np.testing.assert_allclose(normal.cpu().numpy(), ref["normal"], atol=1e-5)
+
+
+# ------------------------------------------------------------------ observed crops
+@pytest.mark.parametrize("mode", ["refine", "score"])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_warp_crops(scene, dev, frame, mode, normalize):
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    P = scene["poses"][::5].copy()
+    P[0, :3, 3] = [0.17, 0.12, 0.6]      # window partly outside the frame: zero padding path
+    P[1, :3, 3] = [-0.14, -0.1, 0.5]
+    tf, _ = oo.crop_windows(P, scene["K"], scene["diameter"], 1.2, (160, 160))
+    m = oo.MODE_REFINE if mode == "refine" else oo.MODE_SCORE
+    ref = oo.warp_crops(scene["rgb"], frame["xyz"] if mode == "refine" else None, frame["depth_f"], tf, scene["K"], P,
+                        scene["diameter"], m, normalize)
+    out = ops.warp_crops(frame["rgb_t"], frame["xyz_t"] if mode == "refine" else None, frame["depth_t"], _t(tf, dev),
+                         scene["K"], _t(P, dev), scene["diameter"], m, normalize).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)
+    assert np.abs(ref[0, :3]).max() > 0 and (ref[0, :3] == 0).mean() > 0.05  # the padded region really is exercised
+    o16 = ops.warp_crops(frame["rgb_t"], frame["xyz_t"] if mode == "refine" else None, frame["depth_t"], _t(tf, dev),
+                         scene["K"], _t(P, dev), scene["diameter"], m, normalize, out_f16=True).cpu().numpy()
+    np.testing.assert_allclose(o16.astype(np.float32), ref, atol=2e-3, rtol=1e-3)
+
+
+# ------------------------------------------------------------------ MFMA kernels vs fp32 torch reference
+def test_conv7x7_mfma(dev):
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.rand((5, 6, 160, 160), generator=g) * 2 - 1)
+    w = torch.randn((64, 6, 7, 7), generator=g) * 0.06
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.2
+    x16, w16 = x.half(), w.half()
+    ref = torch.relu(torch.nn.functional.conv2d(x16.float(), w16.float(), None, stride=2, padding=3)
+                     * scale[None, :, None, None] + shift[None, :, None, None])
+    for cl in (False, True):
+        y = ops.conv7x7s2_bn_relu(x16.to(dev), w16.reshape(64, -1).contiguous().to(dev), scale.to(dev), shift.to(dev),
+                                  channels_last=cl)
+        assert y.shape == (5, 64, 80, 80)
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=2e-3)  # fp16 output rounding
+
+
+@pytest.mark.parametrize("M,K,N", [(800, 512, 1536), (1000, 512, 512), (37, 64, 128)])
+def test_linear_mfma(dev, M, K, N):
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M)
+    x = torch.randn((M, K), generator=g).half()
+    # asymmetric weight so that a transposed fragment layout cannot pass
+    w = (torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-4).half()
+    b = torch.randn(N, generator=g)
+    ref = x.float() @ w.float().t() + b
+    y = ops.linear_f16(x.to(dev), w.to(dev), b.to(dev))
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=4e-3)
+    yr = ops.linear_f16(x.to(dev), w.to(dev), b.to(dev), relu=True)
+    np.testing.assert_allclose(yr.float().cpu().numpy(), torch.relu(ref).numpy(), atol=2e-2, rtol=4e-3)
+
+
+# ------------------------------------------------------------------ predictors end to end (fp32 parity configuration)
+def _geodesic(Ra, Rb):
+    """rotation angle of Ra Rb^T via atan2(sin, cos): well conditioned near 0, unlike arccos of a float32 trace"""
+    D = Ra.astype(np.float64) @ Rb.astype(np.float64).transpose(0, 2, 1)
+    s = 0.5 * np.linalg.norm(np.stack([D[:, 2, 1] - D[:, 1, 2], D[:, 0, 2] - D[:, 2, 0], D[:, 1, 0] - D[:, 0, 1]], 1), axis=1)
+    c = (np.trace(D, axis1=1, axis2=2) - 1) / 2
+    return np.arctan2(s, c)
+
+
+def test_refiner_fp32_matches_oracle(scene, dev, gmesh, frame):
+    """north-star tolerance: dR <= 1e-4 rad, dt <= 1e-4 m after every one of the 3 chained iterations"""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    from oracle import pipeline as op
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = random_state_dict("refine", cfg, seed=0)
+    P0 = scene["poses"][::16]  # 16 hypotheses
+    trace = []
+    ref = op.refine_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, frame["xyz"], scene["mesh_np"],
+                            scene["diameter"], iteration=3, trace=trace)
+    pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp32")
+    for it in (1, 3):
+        out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"],
+                              mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=it)
+        out = out.cpu().numpy()
+        tgt = trace[it - 1]["poses"]
+        dR = _geodesic(out[:, :3, :3], tgt[:, :3, :3])
+        dt = np.linalg.norm(out[:, :3, 3] - tgt[:, :3, 3], axis=1)
+        assert dR.max() <= 1e-4 and dt.max() <= 1e-4, (it, dR.max(), dt.max())
+    assert np.linalg.norm(ref[:, :3, 3] - P0[:, :3, 3], axis=1).max() > 1e-3  # the update is not a no-op
+
+
+def test_scorer_fp32_matches_oracle(scene, dev, gmesh, frame):
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_SCORE_CFG, random_state_dict
+    from oracle import pipeline as op
+    cfg = dict(DEFAULT_SCORE_CFG)
+    sd = random_state_dict("score", cfg, seed=0)
+    P0 = scene["poses"][::16]
+    ref = op.score_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, scene["mesh_np"], scene["diameter"])
+    pred = ScorePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp32")
+    out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, mesh=scene["mesh"], mesh_tensors=gmesh,
+                          mesh_diameter=scene["diameter"])
+    out = out.cpu().numpy()
+    assert np.abs(out - ref).max() < 1e-3 * max(1.0, np.abs(ref - 100).max())
+    spread = ref.max() - ref.min()
+    if spread > 1e-2:  # ranking is only meaningful when the logits are separated by more than the tolerance
+        assert np.argmax(out) == np.argmax(ref)
+
+
+def test_refiner_fp16_plan_close_to_fp32(scene, dev, gmesh, frame):
+    """deployment configuration (fp16 + MFMA kernels) stays close to the fp32 parity configuration (one iteration)"""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = random_state_dict("refine", cfg, seed=0)
+    P0 = scene["poses"][::16]
+    outs = {}
+    for prec in ("fp32", "fp16"):
+        pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision=prec)
+        o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"],
+                            mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=1)
+        outs[prec] = o.cpu().numpy()
+    dt = np.linalg.norm(outs["fp16"][:, :3, 3] - outs["fp32"][:, :3, 3], axis=1)
+    dR = _geodesic(outs["fp16"][:, :3, :3], outs["fp32"][:, :3, :3])
+    assert dt.max() < 2e-3 and dR.max() < 2e-2, (dt.max(), dR.max())
+
+
+def test_estimator_api_sequence(scene, dev):
+    """replays run_demo.py's call sequence: register on frame 0, then track_one (estimater.py:159-268)"""
+    from foundationpose_amd.estimater import FoundationPose
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    mesh = scene["mesh"]
+    refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev)
+    scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), device=dev)
+    est = FoundationPose(model_pts=mesh.vertices, model_normals=mesh.vertex_normals, mesh=mesh, scorer=scorer,
+                         refiner=refiner, device=dev)
+    assert est.rot_grid.shape == (252, 4, 4)
+    with pytest.raises(RuntimeError):
+        est.track_one(scene["rgb"], scene["depth"], scene["K"], iteration=2)
+    pose = est.register(K=scene["K"], rgb=scene["rgb"], depth=scene["depth"], ob_mask=scene["mask"], iteration=2)
+    assert pose.shape == (4, 4) and np.isfinite(pose).all()
+    assert est.poses.shape == (252, 4, 4) and est.scores.shape == (252,)
+    assert (est.scores[:-1] >= est.scores[1:]).all()
+    p2 = est.track_one(scene["rgb"], scene["depth"], scene["K"], iteration=2)
+    assert p2.shape == (4, 4) and np.isfinite(p2).all()
+    empty = est.register(K=scene["K"], rgb=scene["rgb"], depth=scene["depth"], ob_mask=np.zeros_like(scene["mask"]))
+    assert np.allclose(empty[:3, :3], np.eye(3))  # degenerate-mask early-out (estimater.py:185-189)
