@@ -25,6 +25,19 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 REFINE_GFLOP_PER_HYP = 23.946
 SCORE_GFLOP_PER_HYP = 21.938
 SCORE_GFLOP_CROSS_252 = 0.659
+# roofline that bounds each hand-written kernel (DESIGN.md "Kernels")
+KERNEL_BOUND = {"fp_render_crops": "hbm", "fp_warp_crops": "hbm", "fp_conv7x7s2_bn_relu_fwd": "hbm",
+                "fp_linear_f16_fwd": "mfma", "fp_conv3x3_fwd": "mfma", "fp_attention_fwd": "mfma"}
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    scripts/pmc_traffic.py with the gfx950 FETCH_SIZE x2 correction); None when that kernel was not profiled."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
 def build_scene(dev, seed, n_hyp):
@@ -48,7 +61,11 @@ def build_scene(dev, seed, n_hyp):
     return dict(mesh=mesh, gm=gm, K=K, rgb=rgb, depth=d, mask=mask, poses=grid.astype(np.float32), diameter=diameter, T=T)
 
 
-def cpu_baseline(n_hyp=16, iters=5):
+def _log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(n_hyp=8, iters=5):
     """oracle (C rasteriser/warp with OpenMP + torch-CPU fp32 networks) on BASELINE configs[0]; checker, not product"""
     from foundationpose_amd import synthetic as syn
     from foundationpose_amd.Utils import euler_matrix, sample_views_icosphere
@@ -69,8 +86,9 @@ def cpu_baseline(n_hyp=16, iters=5):
     diam = float(np.linalg.norm(mesh.vertices.max(0) - mesh.vertices.min(0)))
     rcfg, scfg = dict(DEFAULT_REFINE_CFG), dict(DEFAULT_SCORE_CFG)
     rsd, ssd = random_state_dict("refine", rcfg, 0), random_state_dict("score", scfg, 0)
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32)
     torch.set_num_threads(cores)
+    oo.set_num_threads(cores)
     d = op.preprocess_depth(depth)
     xyz = oo.depth2xyzmap(d, K)
     op.refine_predict(rcfg, rsd, rgb, d, K, poses[:2], xyz, mnp, diam, iteration=1)  # warm-up
@@ -112,7 +130,10 @@ def main():
     from foundationpose_amd.predict_score import ScorePredictor
     from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
 
+    import faulthandler
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     N, R = args.hyps, args.refine_iters
+    _log("building scene")
     sc = build_scene(dev, seed=rank, n_hyp=N)
     opts = dict(device=dev, precision=args.precision, channels_last=not args.nchw, use_hip_gemm=not args.no_hip_gemm)
     refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), **opts)
@@ -121,7 +142,7 @@ def main():
     depth_t = ops.bilateral_filter_depth(ops.erode_depth(torch.as_tensor(sc["depth"], device=dev)))
     xyz_t = ops.depth_to_xyz(depth_t, sc["K"], f64_internal=True)
     poses0 = torch.as_tensor(sc["poses"], device=dev)
-    gather_buf = [torch.empty((N, 17), device=dev) for _ in range(world)] if world > 1 else None
+    from foundationpose_amd.dist import gather_object_records
 
     def step():
         p, _ = refiner.predict(rgb_t, depth_t, sc["K"], poses0, xyz_t, mesh=sc["mesh"], mesh_tensors=sc["gm"],
@@ -129,19 +150,18 @@ def main():
         s, _ = scorer.predict(rgb_t, depth_t, sc["K"], p, mesh=sc["mesh"], mesh_tensors=sc["gm"],
                               mesh_diameter=sc["diameter"])
         ids = s.argsort(descending=True)
-        rec = torch.cat([s[ids, None], p[ids].reshape(N, 16)], dim=1)  # fused record: scores || refined poses
-        if world > 1:
-            dist.all_gather(gather_buf, rec)   # ONE RCCL all-gather per register()
-        return rec
+        return gather_object_records(s[ids], p[ids])  # ONE RCCL all-gather of [score|pose] per register()
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    _log("warmup (first step compiles the MIOpen kernels)")
     for _ in range(args.warmup):
         step()
     sync()
+    _log("timed region")
     timers = ops.KernelTimers()
     t0 = time.perf_counter()
     with timers:
@@ -158,17 +178,30 @@ def main():
     if rank == 0:
         ksum = timers.summary()
         V, T = sc["gm"]["_handle"].V, sc["gm"]["_handle"].T
-        esz = 2 if args.precision == "fp16" else 4
-        # algorithmic bytes per launch: A output + mesh read once per hypothesis
-        render_bytes = N * (6 * 160 * 160 * esz + 32 * V + 12 * T)
-        warp_bytes = N * 6 * 160 * 160 * esz + 480 * 640 * 24
-        stage_bytes = render_bytes + warp_bytes
         kern = {}
-        for name, (calls, ms) in ksum.items():
-            kern[name] = dict(calls=calls, avg_ms=round(ms, 5))
-        r_ms = ksum.get("fp_render_crops", (0, float("nan")))[1]
-        w_ms = ksum.get("fp_warp_crops", (0, float("nan")))[1]
-        ach = render_bytes / (r_ms * 1e-3) / 1e9
+        for name, k in ksum.items():
+            ent = dict(calls=k["calls"], avg_ms=round(k["avg_ms"], 5))
+            sec = k["avg_ms"] * 1e-3
+            if k["bytes"] > 0 and sec > 0:
+                ent["algorithmic_bytes"] = int(k["bytes"])
+                ent["GBps"] = k["bytes"] / sec / 1e9
+                ent["frac_hbm"] = ent["GBps"] / HBM_PEAK_GBS
+            if k["flops"] > 0 and sec > 0:
+                ent["algorithmic_flops"] = k["flops"]
+                ent["TFLOPs"] = k["flops"] / sec / 1e12
+                ent["frac_mfma"] = ent["TFLOPs"] / MFMA_PEAK_TFLOPS
+            kern[name] = ent
+        # dominant hand-written kernel = largest total time inside the timed region
+        dom = max((n for n in ksum if n in KERNEL_BOUND), key=lambda n: ksum[n]["calls"] * ksum[n]["avg_ms"])
+        dk, bound = ksum[dom], KERNEL_BOUND[dom]
+        sec = dk["avg_ms"] * 1e-3
+        if bound == "hbm":
+            ach, peak, unit = dk["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = dk["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+        traffic = measured_traffic(dom)
+        r_ms, w_ms = ksum["fp_render_crops"]["avg_ms"], ksum["fp_warp_crops"]["avg_ms"]
+        stage_bytes = ksum["fp_render_crops"]["bytes"] + ksum["fp_warp_crops"]["bytes"]
         flops = world * N * (R * REFINE_GFLOP_PER_HYP + SCORE_GFLOP_PER_HYP) + world * SCORE_GFLOP_CROSS_252 * (N / 252.0) ** 2
         out = {
             "metric": "pose-hypotheses/sec (raster+refine+score), 252 hyp x 160x160 @ 640x480 RGB-D",
@@ -177,10 +210,11 @@ def main():
             "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: synthetic can (V={V}, T={T}), one 640x480 RGB-D frame per rank, "
                                    f"{N} hypotheses, {R} refine iterations + 1 score pass, 160x160 crops, random-init weights",
-                       "hypotheses_per_gpu": N, "refine_iterations": R, "parallelism": f"object-parallel x{world}, one all-gather/step"},
-            "roofline": {"kernel": "k_render (fp_render_crops: fused vertex+raster+shade+normalise+concat)", "bound": "hbm",
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": render_bytes, "avg_launch_ms": r_ms},
+                       "hypotheses_per_gpu": N, "refine_iterations": R,
+                       "parallelism": f"object-parallel x{world}, one RCCL all-gather of [score|pose] records per step"},
+            "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                         "traffic": traffic, "algorithmic_per_launch": dk["bytes"] if bound == "hbm" else dk["flops"],
+                         "avg_launch_ms": dk["avg_ms"], "launches_timed": dk["calls"]},
             "stage_raster_crop": {"bytes_per_pass": stage_bytes, "ms_per_pass": r_ms + w_ms,
                                   "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,
                                   "frac_of_hbm_peak": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -189,7 +223,9 @@ def main():
             "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:
+            _log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()
+        faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

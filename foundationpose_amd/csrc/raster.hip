@@ -74,6 +74,18 @@ __device__ __forceinline__ void cam_point(const HypConst& h, float vx, float vy,
   zc = fmaf(h.P[8], vx, fmaf(h.P[9], vy, fmaf(h.P[10], vz, h.P[11])));
 }
 
+// unsnapped crop-pixel position of a camera-space point (same expression as project_vertex / the oracle)
+__device__ __forceinline__ void crop_xy(const HypConst& h, float xc, float yc, float zc, float& X, float& Y) {
+  const float iw = 1.0f / zc;
+  const float skyc = h.sk * yc;
+  const float pu = fmaf(h.fx, xc, skyc);
+  const float pv = h.fy * yc;
+  const float u = fmaf(pu, iw, h.cx);
+  const float v = fmaf(pv, iw, h.cy);
+  X = (u - h.umin) * h.ax;
+  Y = (v - h.vmin) * h.ay;
+}
+
 __device__ __forceinline__ VtxRec project_vertex(const HypConst& h, float vx, float vy, float vz) {
   float xc, yc, zc;
   cam_point(h, vx, vy, vz, xc, yc, zc);
@@ -248,30 +260,32 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_render(
     if (covered) {
       const int t = (int)(uint32_t)(key & 0xFFFFFFFFull);
       tid_out = t;
-      int f[3] = {m.faces[t * 3], m.faces[t * 3 + 1], m.faces[t * 3 + 2]};
-      const VtxRec r0 = vsrc[f[0]], r1 = vsrc[f[1]], r2 = vsrc[f[2]];
-      TriSetup tr;
-      tri_setup(r0, r1, r2, tr);
-      int w0, w1, w2;
-      tri_weights(tr, 16 * i + 8, 16 * j + 8, w0, w1, w2);
-      const int fa0 = f[0], fa1 = f[tr.s1], fa2 = f[tr.s2];
-      const float iw0 = r0.iw;
-      const float iw1 = (tr.s1 == 1) ? r1.iw : r2.iw;
-      const float iw2 = (tr.s1 == 1) ? r2.iw : r1.iw;
-      const float g0 = (float)w0 * iw0, g1 = (float)w1 * iw1, g2 = (float)w2 * iw2;
-      const float S = fmaf((float)w2, iw2, fmaf((float)w1, iw1, (float)w0 * iw0));
-      const float rS = 1.0f / S;
-      const float b0 = g0 * rS, b1 = g1 * rS, b2 = g2 * rS;
-      float q0[3], q1[3], q2[3];
+      const int f[3] = {m.faces[t * 3], m.faces[t * 3 + 1], m.faces[t * 3 + 2]};
+      // nvdiffrast's per-pixel pass: perspective-correct barycentrics of the winner from its
+      // UNSNAPPED vertices in face order, p_k = z_k * (X_k - pixel centre), a0 = p1 x p2, ..., clamped (u, v), 1-u-v
+      const int fa0 = f[0], fa1 = f[1], fa2 = f[2];
+      float q0[3], q1[3], q2[3], X0, Y0, X1, Y1, X2, Y2;
       cam_point(h, m.pos[fa0 * 3], m.pos[fa0 * 3 + 1], m.pos[fa0 * 3 + 2], q0[0], q0[1], q0[2]);
       cam_point(h, m.pos[fa1 * 3], m.pos[fa1 * 3 + 1], m.pos[fa1 * 3 + 2], q1[0], q1[1], q1[2]);
       cam_point(h, m.pos[fa2 * 3], m.pos[fa2 * 3 + 1], m.pos[fa2 * 3 + 2], q2[0], q2[1], q2[2]);
+      crop_xy(h, q0[0], q0[1], q0[2], X0, Y0);
+      crop_xy(h, q1[0], q1[1], q1[2], X1, Y1);
+      crop_xy(h, q2[0], q2[1], q2[2], X2, Y2);
+      const float fxp = (float)i + 0.5f, fyp = (float)j + 0.5f;
+      const float p0x = (X0 - fxp) * q0[2], p0y = (Y0 - fyp) * q0[2];
+      const float p1x = (X1 - fxp) * q1[2], p1y = (Y1 - fyp) * q1[2];
+      const float p2x = (X2 - fxp) * q2[2], p2y = (Y2 - fyp) * q2[2];
+      const float m0a = p1x * p2y, m0b = p1y * p2x, m1a = p2x * p0y, m1b = p2y * p0x, m2a = p0x * p1y, m2b = p0y * p1x;
+      const float a0 = m0a - m0b, a1 = m1a - m1b, a2 = m2a - m2b;
+      const float iwb = 1.0f / ((a0 + a1) + a2);
+      const float b0 = clamp01(a0 * iwb), b1 = clamp01(a1 * iwb);
+      const float b2 = (1.0f - b0) - b1;
 #pragma unroll
       for (int c = 0; c < 3; ++c) pt[c] = fmaf(b2, q2[c], fmaf(b1, q1[c], b0 * q0[c]));
       float base[3];
       if (m.tex) {
         const int32_t* fu = (m.uv_idx ? m.uv_idx : m.faces) + (size_t)t * 3;
-        const int ua = fu[0], ub = fu[tr.s1], uc = fu[tr.s2];
+        const int ua = fu[0], ub = fu[1], uc = fu[2];
         float tu = fmaf(b2, m.uv[uc * 2], fmaf(b1, m.uv[ub * 2], b0 * m.uv[ua * 2]));
         float tv = fmaf(b2, m.uv[uc * 2 + 1], fmaf(b1, m.uv[ub * 2 + 1], b0 * m.uv[ua * 2 + 1]));
         tu = tu - floorf(tu);

@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void k_warp(const float* __restrict__ rgb, con
     }
   } else if (q_in) {
     const float cSw = (float)ow / (float)(ow - 1), cSh = (float)oh / (float)(oh - 1);
-    const float ccx = fmaf(sx, (float)qx, tx), ccy = fmaf(sy, (float)qy, ty);
+    // integer window edge => s*(q - left): exactly 0 on the edge, so the -0.5 tie of hop 2 is deterministic
+    const float lfx = rintf(i02), lfy = rintf(i12);
+    const float ccx = (fabsf(i02 - lfx) <= 1e-3f) ? sx * ((float)qx - lfx) : fmaf(sx, (float)qx, tx);
+    const float ccy = (fabsf(i12 - lfy) <= 1e-3f) ? sy * ((float)qy - lfy) : fmaf(sy, (float)qy, ty);
     const int px = nn_index(fmaf(ccx, cSw, -0.5f)), py = nn_index(fmaf(ccy, cSh, -0.5f));
     float z = 0.f;
     if (px >= 0 && px < ow && py >= 0 && py < oh) {

@@ -257,7 +257,9 @@ def cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs):
 # ---------------------------------------------------------------------------------------------------------------
 # optional per-entry-point timing with HIP events on the launch stream (used by bench.py for the roofline numbers)
 class KernelTimers:
-    """with KernelTimers() as t: ...; t.summary() -> {name: (calls, avg_ms)} measured with events on the current stream."""
+    """with KernelTimers() as t: ...; t.summary() -> {name: dict(calls, avg_ms, bytes, flops)}; times come from
+    HIP events recorded on the stream the kernels are launched on; bytes/flops are the ALGORITHMIC work of one
+    launch (DESIGN.md 'Kernels'), averaged over the recorded launches."""
 
     active = None
 
@@ -275,12 +277,43 @@ class KernelTimers:
         torch.cuda.synchronize()
         out = {}
         for name, evs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = (len(ms), float(sum(ms) / max(1, len(ms))))
+            ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+            n = max(1, len(ms))
+            out[name] = dict(calls=len(ms), avg_ms=float(sum(ms) / n), bytes=float(sum(e[2] for e in evs) / n),
+                             flops=float(sum(e[3] for e in evs) / n))
         return out
 
 
-def _timed(name, fn):
+def _esz(t):
+    return t.element_size() if t is not None else 4
+
+
+def _work_render(mesh, poses, bbox2d, K, H, W, out_hw=(160, 160), *a, **k):
+    N = int(poses.shape[0])
+    A = k.get("A_out")
+    esz = _esz(A) if A is not None else (2 if k.get("out_f16") else 4)
+    return N * (6 * out_hw[0] * out_hw[1] * esz + 32 * mesh.V + 12 * mesh.T), 0.0
+
+
+def _work_warp(rgb, xyz_map, depth, tf_to_crops, K, poses, *a, **k):
+    N = int(poses.shape[0])
+    B = k.get("B_out")
+    oh, ow = k.get("out_hw", (160, 160))
+    esz = _esz(B) if B is not None else (2 if k.get("out_f16") else 4)
+    return N * 6 * oh * ow * esz + rgb.shape[0] * rgb.shape[1] * 24, 0.0
+
+
+def _work_conv1(x, *a, **k):
+    Bn, _, H, W = x.shape
+    return Bn * (6 * H * W + 64 * (H // 2) * (W // 2)) * 2 + 64 * 294 * 2, 2.0 * Bn * (H // 2) * (W // 2) * 64 * 294
+
+
+def _work_linear(x, w, *a, **k):
+    M, K, No = x.numel() // x.shape[-1], x.shape[-1], w.shape[0]
+    return 2 * (M * K + No * K + M * No), 2.0 * M * K * No
+
+
+def _timed(name, fn, work=None):
     def wrapper(*a, **k):
         t = KernelTimers.active
         if t is None:
@@ -289,16 +322,17 @@ def _timed(name, fn):
         e0.record()
         r = fn(*a, **k)
         e1.record()
-        t.records.setdefault(name, []).append((e0, e1))
+        by, fl = work(*a, **k) if work is not None else (0.0, 0.0)
+        t.records.setdefault(name, []).append((e0, e1, float(by), float(fl)))
         return r
     wrapper.__name__ = fn.__name__
     wrapper.__doc__ = fn.__doc__
     return wrapper
 
 
-render_crops = _timed("fp_render_crops", render_crops)
-warp_crops = _timed("fp_warp_crops", warp_crops)
+render_crops = _timed("fp_render_crops", render_crops, _work_render)
+warp_crops = _timed("fp_warp_crops", warp_crops, _work_warp)
 crop_windows = _timed("fp_crop_windows", crop_windows)
 pose_update = _timed("fp_pose_update", pose_update)
-conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu)
-linear_f16 = _timed("fp_linear_f16_fwd", linear_f16)
+conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu, _work_conv1)
+linear_f16 = _timed("fp_linear_f16_fwd", linear_f16, _work_linear)

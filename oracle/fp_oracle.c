@@ -6,11 +6,12 @@
  * bench.py's cpu_baseline leg may load this library; the product path
  * (foundationpose_amd/) never does.
  *
- * PARITY STATUS: "parity unpinned" for every function below that restates
- * third-party arithmetic (nvdiffrast rasterize/interpolate/texture, kornia
- * warp_perspective, NVIDIA Warp kernels): the reference ships no tests or
- * golden vectors and those packages are not installed in this container
- * (SURVEY.md 8(c)).  The integer z-buffer is DEFINED here.
+ * PARITY STATUS: pinned against golden vectors minted by the reference's own Python for this path
+ * (tests/golden/pipeline_golden.npz, tests/test_oracle_pipeline_golden.py).  Still "parity unpinned": the
+ * internals of nvdiffrast (rasterize/interpolate/texture), kornia (warp_perspective) and pytorch3d, which are
+ * absent from /root/reference and from this container and are restated from their published semantics
+ * (SURVEY.md App. B); NVIDIA Warp's two depth kernels are restated from their in-tree source (Utils.py:304-395).
+ * The integer z-buffer is DEFINED here.
  *
  * Reference call sites restated (paths relative to /root/reference):
  *   fpo_erode_depth        Utils.py:359-395   (erode_depth_kernel)
@@ -48,6 +49,14 @@
 #define FPO_FLAG_NORMALIZE_XYZ 1
 #define FPO_MODE_REFINE 0
 #define FPO_MODE_SCORE 1
+
+void fpo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 int fpo_num_threads(void) {
 #ifdef _OPENMP
@@ -199,7 +208,8 @@ void fpo_crop_windows(const float* poses, const double* K, double mesh_diameter,
 
 /* ------------------------------------------------------------------ a8 */
 typedef struct {
-  int32_t xi, yi;
+  int32_t xi, yi;       /* crop-pixel position snapped to 1/16 px (coverage + integer depth key) */
+  float X, Y;           /* unsnapped crop-pixel position (per-pixel barycentrics, nvdiffrast semantics B.1) */
   float iw;
   float xc, yc, zc;
   int valid;
@@ -313,6 +323,8 @@ void fpo_render_crops(const float* pos, const float* nrm, const int* faces, cons
         ok = ok && (xs >= (float)FPO_GUARD_LO) && (xs <= (float)FPO_GUARD_HI) &&
              (ys >= (float)FPO_GUARD_LO) && (ys <= (float)FPO_GUARD_HI);
         o->valid = ok;
+        o->X = X;
+        o->Y = Y;
         o->iw = iw;
         o->xi = ok ? (int32_t)xs : 0;
         o->yi = ok ? (int32_t)ys : 0;
@@ -364,17 +376,22 @@ void fpo_render_crops(const float* pos, const float* nrm, const int* faces, cons
           if (covered) {
             tid = (int32_t)(uint32_t)(key & 0xFFFFFFFFu);
             const int* f = faces + (size_t)tid * 3;
-            fpo_tri tr;
-            tri_setup(vt, f, &tr);
-            int32_t w0, w1, w2;
-            tri_weights(&tr, 16 * i + 8, 16 * j + 8, &w0, &w1, &w2);
-            const int slot[3] = {tr.a0, tr.a1, tr.a2};
-            const int fa[3] = {f[slot[0]], f[slot[1]], f[slot[2]]};
+            /* nvdiffrast's per-pixel pass: perspective-correct barycentrics of the winner from
+             * its UNSNAPPED vertices, p_k = w_k * (ndc_k - pixel centre) (here in crop-pixel units, which leaves the
+             * ratios unchanged), a0 = p1 x p2, ..., u = a0/(a0+a1+a2), v = a1/(...), both clamped to [0,1];
+             * dr.interpolate uses (u, v, 1-u-v) for the face's vertices in face order. */
+            const int slot[3] = {0, 1, 2};
+            const int fa[3] = {f[0], f[1], f[2]};
             const fpo_vtx *q0 = &vt[fa[0]], *q1 = &vt[fa[1]], *q2 = &vt[fa[2]];
-            float g0 = (float)w0 * q0->iw, g1 = (float)w1 * q1->iw, g2 = (float)w2 * q2->iw;
-            float S = fmaf((float)w2, q2->iw, fmaf((float)w1, q1->iw, (float)w0 * q0->iw));
-            float rS = 1.0f / S;
-            float b0 = g0 * rS, b1 = g1 * rS, b2 = g2 * rS;
+            const float fxp = (float)i + 0.5f, fyp = (float)j + 0.5f;
+            const float p0x = (q0->X - fxp) * q0->zc, p0y = (q0->Y - fyp) * q0->zc;
+            const float p1x = (q1->X - fxp) * q1->zc, p1y = (q1->Y - fyp) * q1->zc;
+            const float p2x = (q2->X - fxp) * q2->zc, p2y = (q2->Y - fyp) * q2->zc;
+            const float m0a = p1x * p2y, m0b = p1y * p2x, m1a = p2x * p0y, m1b = p2y * p0x, m2a = p0x * p1y, m2b = p0y * p1x;
+            const float a0 = m0a - m0b, a1 = m1a - m1b, a2 = m2a - m2b;
+            const float iwb = 1.0f / ((a0 + a1) + a2);
+            const float b0 = clamp01(a0 * iwb), b1 = clamp01(a1 * iwb);
+            const float b2 = (1.0f - b0) - b1;
             pt[0] = fmaf(b2, q2->xc, fmaf(b1, q1->xc, b0 * q0->xc));
             pt[1] = fmaf(b2, q2->yc, fmaf(b1, q1->yc, b0 * q0->yc));
             pt[2] = fmaf(b2, q2->zc, fmaf(b1, q1->zc, b0 * q0->zc));
@@ -467,6 +484,11 @@ void fpo_warp_crops(const float* rgb /*H,W,3 0..255*/, const float* xyz_map /*H,
     const float sx = tf[0], tx = tf[2], sy = tf[4], ty = tf[5];
     const float i00 = 1.0f / sx, i11 = 1.0f / sy;
     const float i02 = (-tx) / sx, i12 = (-ty) / sy;
+    /* the crop window's left/top edge is an integer (Utils.py:586-589 round()); when it is, frame -> crop
+     * coordinates are evaluated as s*(q - left): exactly 0 on the window edge, so the half-integer tie of the
+     * scorer's hop 2 (sample coordinate -0.5 for q = left) resolves the same way for every window. */
+    const float lfx = rintf(i02), lfy = rintf(i12);
+    const int alx = fabsf(i02 - lfx) <= 1e-3f, aly = fabsf(i12 - lfy) <= 1e-3f;
     const float* P = poses + (size_t)n * 16;
     const float t0 = P[3], t1 = P[7], t2 = P[11];
     for (int j = 0; j < oh; ++j) {
@@ -497,7 +519,8 @@ void fpo_warp_crops(const float* rgb /*H,W,3 0..255*/, const float* xyz_map /*H,
           if (q_in) { const float* s = xyz_map + ((size_t)qy * W + qx) * 3; pt[0] = s[0]; pt[1] = s[1]; pt[2] = s[2]; }
         } else if (q_in) {
           /* scorer: depth crop -> full frame -> back-projection -> crop (h5_dataset.py:159-161) */
-          float ccx = fmaf(sx, (float)qx, tx), ccy = fmaf(sy, (float)qy, ty);
+          float ccx = alx ? sx * ((float)qx - lfx) : fmaf(sx, (float)qx, tx);
+          float ccy = aly ? sy * ((float)qy - lfy) : fmaf(sy, (float)qy, ty);
           int px = nn_index(fmaf(ccx, cSw, -0.5f)), py = nn_index(fmaf(ccy, cSh, -0.5f));
           float z = 0.f;
           if (px >= 0 && px < ow && py >= 0 && py < oh) {

@@ -40,6 +40,10 @@ def num_threads():
     return int(lib().fpo_num_threads())
 
 
+def set_num_threads(n):
+    lib().fpo_set_num_threads(int(n))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

@@ -1,0 +1,33 @@
+"""Launches every hand-written kernel of libfp_amd.so at the bench sizes (N=252) a few times: the target command of the
+rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in separate passes, see scripts/pmc_traffic.py)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from foundationpose_amd import ops
+
+dev = torch.device("cuda:0")
+N = int(os.environ.get("FP_N", "252"))
+reps = int(os.environ.get("FP_REPS", "3"))
+sc = bench.build_scene(dev, 0, N)
+h = sc["gm"]["_handle"]
+rgb_t = torch.as_tensor(sc["rgb"], device=dev).float().contiguous()
+depth_t = ops.bilateral_filter_depth(ops.erode_depth(torch.as_tensor(sc["depth"], device=dev)))
+xyz_t = ops.depth_to_xyz(depth_t, sc["K"], f64_internal=True)
+poses = torch.as_tensor(sc["poses"], device=dev)
+AB = torch.empty((2 * N, 6, 160, 160), dtype=torch.float16, device=dev)
+g = torch.Generator(device="cpu").manual_seed(0)
+w1 = (torch.randn((64, 294), generator=g) * 0.05).half().to(dev)
+sc1, sh1 = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+x = torch.randn((N * 400, 512), generator=g).half().to(dev)
+wq = (torch.randn((1536, 512), generator=g) * 0.05).half().to(dev)
+bq = torch.zeros(1536, device=dev)
+for _ in range(reps):
+    tf, bb = ops.crop_windows(poses, sc["K"], sc["diameter"], 1.2, (160, 160))
+    ops.render_crops(h, poses, bb, sc["K"], 480, 640, (160, 160), sc["diameter"], 0.001, True, A_out=AB[:N])
+    ops.warp_crops(rgb_t, xyz_t, None, tf, sc["K"], poses, sc["diameter"], ops.MODE_REFINE, True, B_out=AB[N:])
+    ops.warp_crops(rgb_t, None, depth_t, tf, sc["K"], poses, sc["diameter"], ops.MODE_SCORE, True, B_out=AB[N:])
+    y = ops.conv7x7s2_bn_relu(AB, w1, sc1, sh1, channels_last=True)
+    q = ops.linear_f16(x, wq, bq)
+torch.cuda.synchronize()
+print("ok")

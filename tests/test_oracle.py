@@ -77,8 +77,10 @@ def test_raster_watertight_and_analytic_depth(scene):
     cov = tri >= 0
     assert cov.sum() > 20000
     assert (zb[~cov] == 0xFFFFFFFF).all() and (dep[~cov] == 0).all()
-    # fixed-point key consistent with float depth: |zq/2^20 - depth| <= 1 step (+ interpolation rounding)
-    assert np.abs(zb[cov].astype(np.float64) / 2 ** 20 - dep[cov]).max() < 2e-6
+    # fixed-point key (depth at the 1/16-px snapped vertices) vs float depth (unsnapped vertices, nvdiffrast's
+    # per-pixel pass): equal up to the snapping shift (<= 1/32 px of the local depth slope; steep at grazing facets)
+    dz = np.abs(zb[cov].astype(np.float64) / 2 ** 20 - dep[cov])
+    assert np.median(dz) < 2e-5 and np.percentile(dz, 99) < 5e-4 and dz.max() < 5e-3
     # analytic cylinder (r=0.051, h=0.14) intersection along the pixel rays
     vs, us = np.nonzero(cov)
     rays = np.stack([(us + 0.5 - K[0, 2]) / K[0, 0], (vs + 0.5 - K[1, 2]) / K[1, 1], np.ones(len(us))], 1)
