@@ -65,7 +65,7 @@ def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(n_hyp=8, iters=5):
+def cpu_baseline(n_hyp=128, iters=5):
     """oracle (C rasteriser/warp with OpenMP + torch-CPU fp32 networks) on BASELINE configs[0]; checker, not product"""
     from foundationpose_amd import synthetic as syn
     from foundationpose_amd.Utils import euler_matrix, sample_views_icosphere

@@ -30,6 +30,7 @@ SIGNATURES = {
     "fp_pose_update": (ci, [vp, vp, vp, ci, ci, vp, cf, cf, ci, vp, vp]),
     "fp_conv7x7s2_bn_relu_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "fp_linear_f16_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "fp_cluster_poses": (ci, [cf, cf, vp, ci, vp, ci, vp]),
 }
 

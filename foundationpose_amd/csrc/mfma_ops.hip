@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void k_conv7x7s2(const _Float16* __restrict__ 
         float v = (half ? acc1[r] : acc0[r]);
         v = fmaxf(fmaf(v, scale[ch], shift[ch]), 0.f);
         size_t o;
-        if (nhwc) o = (((size_t)b * Hout + oy) * Wout + ox) * 64 + ch;
+        if (nhwc == 2) o = (((size_t)b * (Hout + 2) + oy + 1) * (Wout + 2) + ox + 1) * 64 + ch;  // NHWC with a 1-px zero border
+        else if (nhwc) o = (((size_t)b * Hout + oy) * Wout + ox) * 64 + ch;
         else o = (((size_t)b * 64 + ch) * Hout + oy) * Wout + ox;
         Y[o] = (_Float16)v;
       }

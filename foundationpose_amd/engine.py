@@ -88,17 +88,107 @@ class _Encoder:
         return tok + self.pe[:, : tok.shape[1]]
 
 
+def _igemm_weight(conv):
+    """(Cout, Cin, 3, 3) BN-folded weights -> (Cout, 9*Cin) fp16 with k ordered (ky, kx, ci); bias f32"""
+    w = conv.raw_w * conv.scale[:, None, None, None]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.float16).contiguous(), conv.shift.float().contiguous()
+
+
+class _HipEncoder:
+    """The encoder on libfp_amd.so only: patch-embed conv (fp_conv7x7s2_bn_relu_fwd) + 15 implicit-GEMM 3x3 convs
+    (fp_igemm_f16_fwd) with bias / residual / ReLU epilogues.  Activations are NHWC fp16 with a 1-pixel zero border
+    (allocated once per batch size and reused), the A|B channel concat is a strided store of the stem's last conv
+    (refine_network.py:82-85), and the last conv writes the (N, 400, 512) token matrix directly."""
+
+    def __init__(self, sd, stem, joint, device):
+        mk = lambda c, b, s: _Conv(sd, c, b, s, torch.float16, False)
+        self.c1 = mk(stem + ".0.net.0", stem + ".0.net.1", 2)
+        self.c1_wflat = self.c1.raw_w.to(torch.float16).reshape(64, -1).contiguous()
+        names = [("c2", stem + ".1.net.0", stem + ".1.net.1")]
+        for blk, pre in (("s2", stem + ".2"), ("s3", stem + ".3"), ("j0", joint + ".0"), ("j1", joint + ".1"),
+                         ("j3", joint + ".3"), ("j4", joint + ".4")):
+            names += [(blk + "a", pre + ".conv1", pre + ".bn1"), (blk + "b", pre + ".conv2", pre + ".bn2")]
+        names.append(("j2", joint + ".2.net.0", joint + ".2.net.1"))
+        self.w = {k: _igemm_weight(mk(c, b, 1)) for k, c, b in names}
+        self.pe = sd["pos_embed.pe"].to(torch.float16)
+        self.device = device
+        self._bufs = {}
+
+    def _buffers(self, n, H, W):
+        key = (n, H, W)
+        b = self._bufs.get(key)
+        if b is None:
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=self.device)
+            h1, w1, h2, w2, h3, w3 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+            b = dict(P1=z(2 * n, h1 + 2, w1 + 2, 64), P2=z(2 * n, h2 + 2, w2 + 2, 128), P3=z(2 * n, h2 + 2, w2 + 2, 128),
+                     T=z(2 * n, h2 + 2, w2 + 2, 128), CAT=z(n, h2 + 2, w2 + 2, 256), J0=z(n, h2 + 2, w2 + 2, 256),
+                     T2=z(n, h2 + 2, w2 + 2, 256), Q0=z(n, h3 + 2, w3 + 2, 512), Q1=z(n, h3 + 2, w3 + 2, 512),
+                     T3=z(n, h3 + 2, w3 + 2, 512), dims=(h1, w1, h2, w2, h3, w3))
+            self._bufs = {key: b}   # one batch size resident at a time
+        return b
+
+    def _conv(self, name, x, Bn, Ho, Wo, Cin, Cout, y, stride=1, res=None, relu=True, gout=None, gres=None):
+        w, bias = self.w[name]
+        G = ops.IgemmGeom.image
+        gin = G(Ho, Wo, 1, Cin, stride=stride, offset=0)
+        gout = gout if gout is not None else G(Ho, Wo, 1, Cout)
+        if res is not None and gres is None:
+            gres = G(Ho, Wo, 1, Cout)
+        return ops.igemm_f16(x, gin, w, bias, y, gout, Bn * Ho * Wo, Cout, Cin, 9, relu=relu, residual=res, r_geom=gres)
+
+    def __call__(self, AB):
+        n2, _, H, W = AB.shape
+        n = n2 // 2
+        b = self._buffers(n, H, W)
+        h1, w1, h2, w2, h3, w3 = b["dims"]
+        G = ops.IgemmGeom.image
+        ops.conv7x7s2_bn_relu(AB, self.c1_wflat, self.c1.scale, self.c1.shift, out_padded=b["P1"])
+        self._conv("c2", b["P1"], n2, h2, w2, 64, 128, b["P2"], stride=2)
+        self._conv("s2a", b["P2"], n2, h2, w2, 128, 128, b["T"])
+        self._conv("s2b", b["T"], n2, h2, w2, 128, 128, b["P3"], res=b["P2"])
+        self._conv("s3a", b["P3"], n2, h2, w2, 128, 128, b["T"])
+        # stem output of image i (A) and image n+i (B) side by side along C: torch.cat((a, b), 1)
+        self._conv("s3b", b["T"], n2, h2, w2, 128, 128, b["CAT"], res=b["P3"],
+                   gout=G(h2, w2, 1, 256, bsplit=n, cgroup=128), gres=G(h2, w2, 1, 128))
+        self._conv("j0a", b["CAT"], n, h2, w2, 256, 256, b["T2"])
+        self._conv("j0b", b["T2"], n, h2, w2, 256, 256, b["J0"], res=b["CAT"])
+        self._conv("j1a", b["J0"], n, h2, w2, 256, 256, b["T2"])
+        self._conv("j1b", b["T2"], n, h2, w2, 256, 256, b["CAT"], res=b["J0"])
+        self._conv("j2", b["CAT"], n, h3, w3, 256, 512, b["Q0"], stride=2)
+        self._conv("j3a", b["Q0"], n, h3, w3, 512, 512, b["T3"])
+        self._conv("j3b", b["T3"], n, h3, w3, 512, 512, b["Q1"], res=b["Q0"])
+        self._conv("j4a", b["Q1"], n, h3, w3, 512, 512, b["T3"])
+        tok = torch.empty((n, h3 * w3, 512), dtype=torch.float16, device=AB.device)
+        self._conv("j4b", b["T3"], n, h3, w3, 512, 512, tok, res=b["Q1"], gout=G(h3, w3, 0, 512), gres=G(h3, w3, 1, 512))
+        return tok + self.pe[:, : tok.shape[1]]
+
+
 class _Linear:
     def __init__(self, w, b, dtype, use_hip):
-        self.use_hip = use_hip and dtype == torch.float16 and w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0
+        self.use_hip = use_hip and dtype == torch.float16 and w.shape[0] % 128 == 0 and w.shape[1] % 64 == 0
         self.w = w.to(dtype).contiguous()
         self.b32 = b.float().contiguous()
         self.b = b.to(dtype)
 
-    def __call__(self, x, relu=False):
+    def __call__(self, x, relu=False, residual=None):
+        """y = act(x @ w.T + b (+ residual)); the fp16 plan runs it on fp_igemm_f16_fwd with the epilogue fused"""
         if self.use_hip:
-            return ops.linear_f16(x.contiguous(), self.w, self.b32, relu=relu)
+            x2 = x.reshape(-1, x.shape[-1])
+            x2 = x2 if x2.is_contiguous() else x2.contiguous()
+            M, K = x2.shape
+            No = self.w.shape[0]
+            y = torch.empty((M, No), dtype=torch.float16, device=x.device)
+            r2 = None
+            if residual is not None:
+                r2 = residual.reshape(-1, No)
+                r2 = r2 if r2.is_contiguous() else r2.contiguous()
+            Gm = ops.IgemmGeom.matrix
+            ops.igemm_f16(x2, Gm(K), self.w, self.b32, y, Gm(No), M, No, K, 1, relu=relu, residual=r2,
+                          r_geom=Gm(No) if r2 is not None else None)
+            return y.reshape(*x.shape[:-1], No)
         y = F.linear(x, self.w, self.b)
+        if residual is not None:
+            y = y + residual
         return F.relu_(y) if relu else y
 
 
@@ -110,7 +200,7 @@ class _MHA:
         self.out = _Linear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"], dtype, use_hip)
         self.nhead = nhead
 
-    def __call__(self, x):
+    def __call__(self, x, residual=None):
         Bn, L, D = x.shape
         hd = D // self.nhead
         qkv = self.qkv(x).reshape(Bn, L, 3, self.nhead, hd)
@@ -118,7 +208,7 @@ class _MHA:
         # fused attention: the (Bn*4, L, L) probability tensor (161 M elements at N=252, which the reference
         # materialises because it calls nn.MultiheadAttention with need_weights=True) never reaches HBM
         o = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(Bn, L, D)
-        return self.out(o)
+        return self.out(o, residual=residual)
 
 
 class _EncoderLayer:
@@ -136,8 +226,8 @@ class _EncoderLayer:
         return F.layer_norm(x.float(), (x.shape[-1],), wb[0], wb[1], 1e-5).to(self.dtype)
 
     def __call__(self, x):
-        x = self._ln(x + self.att(x), self.n1)
-        return self._ln(x + self.l2(self.l1(x, relu=True)), self.n2)
+        x = self._ln(self.att(x, residual=x), self.n1)
+        return self._ln(self.l2(self.l1(x, relu=True), residual=x), self.n2)
 
 
 def _dev_sd(module_or_sd, device):
@@ -149,7 +239,9 @@ class RefinePlan:
     def __init__(self, model, device, precision="fp16", channels_last=True, use_hip=True):
         sd = _dev_sd(model, device)
         self.dtype = torch.float16 if precision == "fp16" else torch.float32
-        self.enc = _Encoder(sd, "encodeA", "encodeAB", self.dtype, channels_last, use_hip)
+        hip = use_hip and self.dtype == torch.float16
+        self.enc = _HipEncoder(sd, "encodeA", "encodeAB", device) if hip else \
+            _Encoder(sd, "encodeA", "encodeAB", self.dtype, channels_last, use_hip)
         self.heads = {}
         for name in ("trans", "rot"):
             self.heads[name] = (_EncoderLayer(sd, f"{name}_head.0", self.dtype, use_hip),
@@ -168,7 +260,9 @@ class ScorePlan:
     def __init__(self, model, device, precision="fp16", channels_last=True, use_hip=True):
         sd = _dev_sd(model, device)
         self.dtype = torch.float16 if precision == "fp16" else torch.float32
-        self.enc = _Encoder(sd, "encoderA", "encoderAB", self.dtype, channels_last, use_hip)
+        hip = use_hip and self.dtype == torch.float16
+        self.enc = _HipEncoder(sd, "encoderA", "encoderAB", device) if hip else \
+            _Encoder(sd, "encoderA", "encoderAB", self.dtype, channels_last, use_hip)
         self.att = _MHA(sd, "att", self.dtype, use_hip)
         self.att_cross = _MHA(sd, "att_cross", self.dtype, use_hip)
         self.lin_w, self.lin_b = sd["linear.weight"].to(self.dtype), sd["linear.bias"].to(self.dtype)

@@ -212,8 +212,9 @@ def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, tra
     return O
 
 
-def conv7x7s2_bn_relu(x, w_flat, scale, shift, channels_last=False):
-    """x (B,6,H,W) f16 NCHW -> (B,64,H/2,W/2) f16 (logical NCHW; channels_last memory format if asked)."""
+def conv7x7s2_bn_relu(x, w_flat, scale, shift, channels_last=False, out_padded=None):
+    """x (B,6,H,W) f16 NCHW -> (B,64,H/2,W/2) f16 (logical NCHW; channels_last memory format if asked).
+    out_padded: a zero-bordered (B, H/2+2, W/2+2, 64) NHWC buffer to write the interior of (returned as is)."""
     x = _dev(x, torch.float16, "x")
     w = _dev(w_flat, torch.float16, "w")
     sc = _dev(scale, torch.float32, "scale")
@@ -221,12 +222,18 @@ def conv7x7s2_bn_relu(x, w_flat, scale, shift, channels_last=False):
     Bn, Cin, H, W = x.shape
     if Cin != 6:
         raise _lib.FpAmdError("conv7x7s2_bn_relu: C_in must be 6")
-    if channels_last:
+    mode = 1 if channels_last else 0
+    if out_padded is not None:
+        y = _dev(out_padded, torch.float16, "out_padded")
+        if tuple(y.shape) != (Bn, H // 2 + 2, W // 2 + 2, 64):
+            raise _lib.FpAmdError(f"conv7x7s2_bn_relu: out_padded has shape {tuple(y.shape)}")
+        mode = 2
+    elif channels_last:
         y = torch.empty((Bn, 64, H // 2, W // 2), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     else:
         y = torch.empty((Bn, 64, H // 2, W // 2), dtype=torch.float16, device=x.device)
     st = _lib.lib().fp_conv7x7s2_bn_relu_fwd(_ptr(x), _ptr(w), _ptr(sc), _ptr(sh), _ptr(y), int(Bn), int(H), int(W),
-                                             int(bool(channels_last)), _stream())
+                                             mode, _stream())
     _lib.check(st, "fp_conv7x7s2_bn_relu_fwd")
     return y
 
@@ -242,6 +249,41 @@ def linear_f16(x, w, bias=None, relu=False):
     st = _lib.lib().fp_linear_f16_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), int(M), int(K), Nout, int(bool(relu)), _stream())
     _lib.check(st, "fp_linear_f16_fwd")
     return y.reshape(*x.shape[:-1], Nout)
+
+
+class IgemmGeom(C.Structure):
+    """fp_igemm_geom (include/fp_amd.h): addressing of one NHWC fp16 operand of fp_igemm_f16_fwd"""
+    _fields_ = [(n, C.c_int) for n in ("pixels_per_image", "width", "padded_h", "padded_w", "stride", "offset", "cstride",
+                                       "coff", "bsplit", "cgroup")]
+
+    @staticmethod
+    def matrix(ld):
+        return IgemmGeom(1, 1, 1, 1, 1, 0, int(ld), 0, 0, 0)
+
+    @staticmethod
+    def image(Ho, Wo, pad, C_, stride=1, offset=None, coff=0, bsplit=0, cgroup=0):
+        """rows = output pixels (Ho x Wo per image) addressed in a buffer (B, Ho*stride + 2*pad, Wo*stride + 2*pad, C_)
+        (for stride 1 that is the output / residual buffer itself; for the conv INPUT pass offset=0 so that the
+        geometry addresses tap (0,0))"""
+        return IgemmGeom(Ho * Wo, Wo, Ho * stride + 2 * pad, Wo * stride + 2 * pad, stride, pad if offset is None else offset,
+                         C_, coff, bsplit, cgroup)
+
+
+def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None):
+    """y = act(implicit_gemm(x, w) + bias (+ residual)) -- see fp_igemm_f16_fwd.  All tensors fp16 device buffers
+    owned by the caller (y is written in place and returned)."""
+    x = _dev(x, torch.float16, "x"); w = _dev(w, torch.float16, "w"); y = _dev(y, torch.float16, "y")
+    b = _dev(bias, torch.float32, "bias"); r = _dev(residual, torch.float16, "residual")
+    st = _lib.lib().fp_igemm_f16_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(b), _ptr(r),
+                                     C.byref(r_geom) if r_geom is not None else None, _ptr(y), C.byref(y_geom), int(M), int(N),
+                                     int(Cin), int(taps), int(bool(relu)), _stream())
+    _lib.check(st, "fp_igemm_f16_fwd")
+    return y
+
+
+def _work_igemm(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None):
+    by = 2 * (M * Cin * (1 if taps == 1 else 1.0 / (x_geom.stride ** 2)) + N * Cin * taps + M * N * (2 if residual is not None else 1))
+    return by, 2.0 * M * N * Cin * taps
 
 
 def cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs):
@@ -336,3 +378,4 @@ crop_windows = _timed("fp_crop_windows", crop_windows)
 pose_update = _timed("fp_pose_update", pose_update)
 conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu, _work_conv1)
 linear_f16 = _timed("fp_linear_f16_fwd", linear_f16, _work_linear)
+igemm_f16 = _timed("fp_igemm_f16_fwd", igemm_f16, _work_igemm)

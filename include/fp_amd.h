@@ -114,7 +114,9 @@ int fp_pose_update(const float* trans /*dev N,3*/, const float* rot /*dev N,3|6*
 /* refine_network.py:38 / score_network.py:37 first ConvBNReLU (7x7, stride 2, pad 3, C_in -> 64) with the
  * eval-mode BatchNorm folded into (scale, shift) and ReLU fused: the "patch-embed conv" as an MFMA implicit GEMM.
  * x (B,6,160,160) f16 NCHW ; w (64, 6*7*7) f16 row-major (PyTorch conv weight flattened) ;
- * scale/shift (64) f32 : y = relu(conv(x,w) * scale + shift) ; y (B,64,80,80) f16, NCHW or NHWC (channels_last). */
+ * scale/shift (64) f32 : y = relu(conv(x,w) * scale + shift) ; y (B,64,80,80) f16; channels_last_out = 0: NCHW,
+ * 1: NHWC, 2: NHWC inside a (B,82,82,64) buffer with a 1-pixel border the kernel does not touch (the input layout
+ * of fp_igemm_f16_fwd). */
 int fp_conv7x7s2_bn_relu_fwd(const void* x /*dev*/, const void* w /*dev*/, const float* scale /*dev*/,
                              const float* shift /*dev*/, void* y /*dev*/, int B, int Hin, int Win,
                              int channels_last_out, void* stream);
@@ -125,6 +127,27 @@ int fp_conv7x7s2_bn_relu_fwd(const void* x /*dev*/, const void* w /*dev*/, const
 int fp_linear_f16_fwd(const void* x /*dev M,K f16*/, const void* w /*dev Nout,K f16*/,
                       const float* bias /*dev Nout f32|NULL*/, void* y /*dev M,Nout f16*/, int M, int K, int Nout,
                       int relu, void* stream);
+
+/* Addressing of one operand of fp_igemm_f16_fwd: GEMM row m = (image b, oy, ox) with b = m / pixels_per_image,
+ * oy = (m % pixels_per_image) / width, ox = ... % width, lives at element offset
+ *   (((b' * padded_h + oy*stride + offset) * padded_w + ox*stride + offset) * cstride + coff + cg * cgroup
+ * of an NHWC fp16 buffer with a zero border, where (b', cg) = (b % bsplit, b / bsplit) if bsplit > 0 else (b, 0)
+ * (bsplit writes the A- and B-image features of a pair side by side along C: the channel concat of
+ * refine_network.py:82-85 / score_network.py:66-69 without a copy).  A plain matrix is {1,1,1,1,1,0,ld,0,0,0}. */
+typedef struct {
+  int pixels_per_image, width, padded_h, padded_w, stride, offset, cstride, coff, bsplit, cgroup;
+} fp_igemm_geom;
+
+/* network_modules.py:37-50 ConvBNReLU / :73-111 ResnetBasicBlock (3x3, pad 1, stride 1|2; eval BatchNorm folded into
+ * w and bias) and the 512-wide Linear layers of refine_network.py:56-70 / score_network.py:52-53, as ONE MFMA
+ * implicit GEMM:  y[m, n] = act( sum_{tap, ci} x[row(m) + tap][ci] * w[n][tap*Cin + ci] + bias[n] (+ residual[m, n]) ).
+ * x / y / residual: NHWC fp16 addressed by their fp_igemm_geom (the input's border must be zero; its geometry
+ * addresses tap (0,0), i.e. offset = 0 for pad 1); w (N, taps*Cin) fp16 with k ordered (ky, kx, ci); bias (N) f32.
+ * taps = 9 (3x3) or 1 (GEMM); N % 128 == 0; Cin % 64 == 0. */
+int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/,
+                     const float* bias /*dev|NULL*/, const void* residual /*dev|NULL*/,
+                     const fp_igemm_geom* r_geom /*host|NULL*/, void* y /*dev*/, const fp_igemm_geom* y_geom /*host*/,
+                     int M, int N, int Cin, int taps, int relu, void* stream);
 
 /* mycpp/src/app/pybind_api.cpp:24-68 cluster_poses (host, init-time). Returns #kept, indices in keep_idx. */
 int fp_cluster_poses(float angle_diff_deg, float dist_diff, const float* poses /*host N,16*/, int N,

@@ -350,3 +350,113 @@ def test_estimator_api_sequence(scene, dev):
     assert p2.shape == (4, 4) and np.isfinite(p2).all()
     empty = est.register(K=scene["K"], rgb=scene["rgb"], depth=scene["depth"], ob_mask=np.zeros_like(scene["mask"]))
     assert np.allclose(empty[:3, :3], np.eye(3))  # degenerate-mask early-out (estimater.py:185-189)
+
+
+# ------------------------------------------------------------------ HIP path vs the reference's own Python (golden vectors)
+def test_hip_network_inputs_match_reference_golden(scene, dev, gmesh, frame):
+    """fp_crop_windows + fp_render_crops + fp_warp_crops against tests/golden/pipeline_golden.npz, which was produced
+    by the reference's make_crop_data_batch / transform_batch (tolerances: tests/test_oracle_pipeline_golden.py)"""
+    import os
+    from foundationpose_amd import ops
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_golden.npz")))
+    P = _t(g["poses_in"], dev)
+    tf, bb = ops.crop_windows(_t(scene["poses"], dev), scene["K"], scene["diameter"], 1.2, (160, 160))
+    assert np.array_equal(tf.cpu().numpy(), g["g1_tf_to_crops"])
+    for mode, ratio, thr, keyA, keyB in ((ops.MODE_REFINE, 1.2, 0.001, "g3_refine_A_norm1", "g3_refine_B_norm1"),
+                                         (ops.MODE_SCORE, 1.1, 0.1, "g3_score_A", "g3_score_B")):
+        tf, bb = ops.crop_windows(P, scene["K"], scene["diameter"], ratio, (160, 160))
+        A = ops.render_crops(gmesh["_handle"], P, bb, scene["K"], 480, 640, (160, 160), scene["diameter"], thr, True,
+                             want=("A",))["A"].cpu().numpy()[:, :, ::2, ::2]
+        B = ops.warp_crops(frame["rgb_t"], frame["xyz_t"] if mode == ops.MODE_REFINE else None, frame["depth_t"], tf,
+                           scene["K"], P, scene["diameter"], mode, True).cpu().numpy()[:, :, ::2, ::2]
+        dA = np.abs(A - g[keyA])
+        assert dA[:, 3:].max() <= 5e-4 and (dA[:, :3] > 1e-3).mean() <= 1e-3 and dA[:, :3].max() <= 0.2
+        np.testing.assert_allclose(B[:, :3], g[keyB][:, :3], rtol=0, atol=1e-4)
+        diff = (B[:, 3:] != g[keyB][:, 3:]).any(1)
+        assert diff.mean() < 2e-3 and diff[:, 1:, 1:].sum() == 0
+
+
+# ------------------------------------------------------------------ implicit-GEMM conv / linear kernel vs fp32 torch
+def _padded_nhwc(x_nchw, pad, dev):
+    B, Cc, H, W = x_nchw.shape
+    buf = torch.zeros((B, H + 2 * pad, W + 2 * pad, Cc), dtype=torch.float16, device=dev)
+    buf[:, pad:pad + H, pad:pad + W, :] = x_nchw.permute(0, 2, 3, 1).to(dev)
+    return buf
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,res", [(3, 40, 128, 128, 1, True), (2, 80, 64, 128, 2, False),
+                                                     (5, 20, 512, 512, 1, True), (3, 40, 256, 512, 2, False)])
+def test_igemm_conv3x3(dev, B, H, Cin, Cout, stride, res):
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin)
+    x = (torch.randn((B, Cin, H, H), generator=g) * 0.5).half()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (1.0 / (3 * Cin ** 0.5)) + torch.arange(Cout)[:, None, None, None] * 1e-5).half()
+    bias = torch.randn(Cout, generator=g) * 0.1
+    Ho = H // stride
+    r = (torch.randn((B, Cout, Ho, Ho), generator=g) * 0.5).half() if res else None
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias, stride=stride, padding=1)
+    ref = ref.half().float()          # torch semantics: conv output rounded to fp16 ...
+    if res:
+        ref = (ref + r.float()).half().float()   # ... then the fp16 residual add
+    ref = torch.relu(ref)
+    xb = _padded_nhwc(x, 1, dev)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dev)
+    y = torch.zeros((B, Ho + 2, Ho + 2, Cout), dtype=torch.float16, device=dev)
+    rb = _padded_nhwc(r, 1, dev) if res else None
+    gin = ops.IgemmGeom.image(Ho, Ho, 1, Cin, stride=stride, offset=0)
+    gin.padded_h, gin.padded_w = H + 2, H + 2
+    gout = ops.IgemmGeom.image(Ho, Ho, 1, Cout)
+    ops.igemm_f16(xb, gin, wk, bias.to(dev), y, gout, B * Ho * Ho, Cout, Cin, 9, relu=True, residual=rb, r_geom=gout if res else None)
+    out = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=6e-3, rtol=4e-3)
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0   # the zero border is left untouched
+
+
+def test_igemm_channel_concat_and_linear(dev):
+    """bsplit writes image b and image b+n side by side along C (the A|B feature concat); taps=1 is a plain GEMM with
+    a ragged last tile"""
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(77)
+    n, H, Cc = 3, 8, 128
+    x = (torch.randn((2 * n, Cc, H, H), generator=g) * 0.5).half()
+    w = (torch.randn((Cc, Cc, 3, 3), generator=g) * 0.03).half()
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, padding=1)
+    ref = torch.cat([ref[:n], ref[n:]], dim=1)
+    y = torch.zeros((n, H + 2, H + 2, 2 * Cc), dtype=torch.float16, device=dev)
+    gin = ops.IgemmGeom.image(H, H, 1, Cc, offset=0)
+    gout = ops.IgemmGeom.image(H, H, 1, 2 * Cc, bsplit=n, cgroup=Cc)
+    ops.igemm_f16(_padded_nhwc(x, 1, dev), gin, w.permute(0, 2, 3, 1).reshape(Cc, -1).contiguous().to(dev), None, y, gout,
+                  2 * n * H * H, Cc, Cc, 9)
+    np.testing.assert_allclose(y[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=4e-3)
+    for M, K, N in ((1000, 512, 1536), (37, 64, 128), (4097, 512, 512)):
+        xm = torch.randn((M, K), generator=g).half()
+        wm = (torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-4).half()
+        b = torch.randn(N, generator=g)
+        refm = xm.float() @ wm.float().t() + b
+        ym = torch.empty((M, N), dtype=torch.float16, device=dev)
+        ops.igemm_f16(xm.to(dev), ops.IgemmGeom.matrix(K), wm.to(dev), b.to(dev), ym, ops.IgemmGeom.matrix(N), M, N, K, 1)
+        np.testing.assert_allclose(ym.float().cpu().numpy(), refm.numpy(), atol=2e-2, rtol=4e-3)
+
+
+@pytest.mark.parametrize("use_bn", [True, False])
+def test_hip_encoder_matches_torch_fp32_encoder(dev, use_bn):
+    """_HipEncoder (conv1 + 15 implicit-GEMM convs, padded NHWC, fused epilogues) vs the fp32 PyTorch encoder"""
+    from foundationpose_amd import engine
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    cfg = dict(DEFAULT_REFINE_CFG, use_BN=use_bn)
+    sd = {k: v.to(dev) for k, v in random_state_dict("refine", cfg, seed=3).items()}
+    g = torch.Generator(device="cpu").manual_seed(8)
+    n = 3
+    AB = torch.rand((2 * n, 6, 160, 160), generator=g)
+    AB[:, 3:] = AB[:, 3:] * 2 - 1
+    AB = AB * (torch.rand((2 * n, 1, 160, 160), generator=g) > 0.3)
+    ref = engine._Encoder(sd, "encodeA", "encodeAB", torch.float32, False, False)(AB.to(dev))
+    enc = engine._HipEncoder(sd, "encodeA", "encodeAB", dev)
+    hip = enc(AB.half().to(dev))
+    assert hip.shape == ref.shape == (n, 400, 512)
+    err = (hip.float() - ref).abs()
+    scale = ref.abs().mean().item()
+    assert err.max().item() <= 0.06 * max(1.0, ref.abs().max().item()) and err.mean().item() <= 5e-3 * max(scale, 1.0), \
+        (err.max().item(), err.mean().item(), scale)
+    # second call reuses the cached zero-bordered buffers: identical result
+    assert torch.equal(hip, enc(AB.half().to(dev)))
