@@ -1,0 +1,205 @@
+// Patch-embed convolution of both encoders (refine_network.py:38, score_network.py:37: ConvBNReLU(6 -> 64, 7x7,
+// stride 2, pad 3)) for gfx950, NHWC output.  HBM-bound by construction (0.48 GFLOP against 1.95 MB per pair of
+// images), so the kernel is organised around streaming:
+//   * persistent workgroups (one per CU): the 64 x 294 weights are loaded ONCE per workgroup, straight from the
+//     PyTorch (64, 6*7*7) layout, into MFMA A-fragments that live in registers for the whole launch
+//     (k re-ordered as (c, ky, kx[8]) = 42 groups of 8 -> 21 k-steps of v_mfma_f32_32x32x16_f16; kx = 7 is a zero weight);
+//   * work unit = (image, band of 8 output rows): its 6 x 21 x (W+16) input patch goes HBM -> LDS by
+//     global_load_lds_dwordx4 (zero padding comes from a 16-byte zero block, so the DMA stays lane-linear), double
+//     buffered: the patch of band t+1 is in flight while band t is multiplied;
+//   * B-fragment of a lane = 8 consecutive input pixels of one (c, ky) row starting at 2*ox - 3: five conflict-free
+//     ds_read_b32 + four v_alignbit (the run starts on an odd element), no im2col, no index table;
+//   * D[channel][pixel] accumulators get BN(scale, shift) + ReLU in fp32, are transposed through a wave-private
+//     swizzled LDS tile and leave as 16-byte stores: 128 contiguous bytes per pixel (all 64 channels).
+#include <hip/hip_fp16.h>
+#include "fp_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16_ __attribute__((ext_vector_type(16)));
+typedef unsigned int uint4_ __attribute__((ext_vector_type(4)));
+
+#define C1_CIN 6
+#define C1_ROWS 8                    // output rows per band
+#define C1_PR (2 * C1_ROWS + 5)      // input rows per band
+#define C1_KS 21                     // k-steps of 16 = 42 (c, ky) groups of 8 kx
+#define C1_THREADS 256
+#define C1_MAXW 256
+
+__device__ __attribute__((aligned(16))) const unsigned int c1_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct Conv1Params {
+  const _Float16* X;     // (B, 6, Hin, Win)
+  const _Float16* W;     // (64, 294)
+  const float* scale;    // (64)
+  const float* shift;    // (64)
+  _Float16* Y;           // (B, Hout + 2*pad, Wout + 2*pad, 64)
+  int B, Hin, Win, Hout, Wout, pad;
+  int bands_per_image, total_bands;
+  int PW;                // patch row length in halves = Win + 16
+};
+
+__device__ __forceinline__ void c1_stage(const Conv1Params& p, int band, unsigned char* patch, int tid) {
+  const int b = band / p.bands_per_image;
+  const int oy0 = (band - b * p.bands_per_image) * C1_ROWS;
+  const int iy0 = 2 * oy0 - 3;
+  const int cpr = p.PW >> 3;                       // 16-byte chunks per patch row
+  const int nchunks = C1_CIN * C1_PR * cpr;
+  const _Float16* Xb = p.X + (size_t)b * C1_CIN * p.Hin * p.Win;
+  const int lane = tid & 63, wid = tid >> 6;
+  // wave-instruction k of this wave covers chunks [64*(4*k + wid), +64): LDS destination is lane-linear
+  for (int base = wid * 64; base < nchunks; base += C1_THREADS) {
+    const int ch = base + lane;
+    const void* src = c1_zero16;
+    if (ch < nchunks) {
+      const int q = ch % cpr, t = ch / cpr;
+      const int r = t % C1_PR, c = t / C1_PR;
+      const int iy = iy0 + r, ix = (q - 1) * 8;   // patch element x = image x + 8
+      if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) src = Xb + ((size_t)c * p.Hin + iy) * p.Win + ix;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(patch + (size_t)base * 16), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(C1_THREADS, 1) void k_conv7x7s2_nhwc(Conv1Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int px = lane & 31, kh = lane >> 5;
+  const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;  // DMA may overrun by < 64 chunks
+  unsigned char* patch0 = smem;
+  unsigned char* patch1 = smem + patch_bytes;
+  unsigned char* etile = smem + 2 * patch_bytes + wid * 4096;   // wave-private 32 px x 64 ch transpose tile
+
+  // ---- weights -> register-resident A fragments: wf[ks][h] = W[h*32 + px][group 2*ks + kh][0..7]
+  half8 wf[C1_KS][2];
+#pragma unroll
+  for (int ks = 0; ks < C1_KS; ++ks) {
+    const int g = 2 * ks + kh;          // (c, ky) group
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const _Float16* w = p.W + (size_t)(h * 32 + px) * 294 + g * 7;   // c*49 + ky*7 == g*7
+#pragma unroll
+      for (int e = 0; e < 7; ++e) wf[ks][h][e] = w[e];
+      wf[ks][h][7] = (_Float16)0.f;
+    }
+  }
+  // BN scale / shift of this lane's 32 output channels: channel = h*32 + 8*g4 + 4*kh + e
+  float sc[2][4][4], sh[2][4][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int chn = h * 32 + 8 * g4 + 4 * kh + e;
+        sc[h][g4][e] = p.scale[chn];
+        sh[h][g4][e] = p.shift[chn];
+      }
+
+  const int band_px = C1_ROWS * p.Wout;
+  const int tiles = (band_px + 31) >> 5;
+  const int row_bytes = p.PW * 2;
+  const int Hp = p.Hout + 2 * p.pad, Wp = p.Wout + 2 * p.pad;
+
+  int band = blockIdx.x;
+  if (band < p.total_bands) c1_stage(p, band, patch0, tid);
+  int cur = 0;
+  for (; band < p.total_bands; band += gridDim.x, cur ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0);     // this band's patch has landed (own DMA) ...
+    __syncthreads();                   // ... and everyone's; everyone is also done reading the other buffer
+    unsigned char* patch = cur ? patch1 : patch0;
+    const int nxt = band + gridDim.x;
+    if (nxt < p.total_bands) c1_stage(p, nxt, cur ? patch0 : patch1, tid);
+    const int b = band / p.bands_per_image;
+    const int oy0 = (band - b * p.bands_per_image) * C1_ROWS;
+    for (int tile = wid; tile < tiles; tile += 4) {
+      int t = tile * 32 + px;
+      t = t < band_px ? t : band_px - 1;
+      const int oyl = t / p.Wout, ox = t - oyl * p.Wout;
+      // lane base: row 2*oyl of channel 0, dword (ox + 2) of the row  [element 2*ox + 5 = image x 2*ox - 3]
+      const unsigned char* lb = patch + (size_t)(2 * oyl) * row_bytes + (ox + 2) * 4;
+      float16_ acc0, acc1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C1_KS; ++ks) {
+        // group g = 2*ks + kh -> (c, ky) = (g / 7, g % 7); both candidates are compile-time constants
+        const int g0 = 2 * ks, g1 = 2 * ks + 1;
+        const int off0 = ((g0 / 7) * C1_PR + (g0 % 7)), off1 = ((g1 / 7) * C1_PR + (g1 % 7));
+        const unsigned int* d = reinterpret_cast<const unsigned int*>(lb + (size_t)(kh ? off1 : off0) * row_bytes);
+        const unsigned int d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+        uint4_ fv;
+        fv[0] = __builtin_amdgcn_alignbit(d1, d0, 16);
+        fv[1] = __builtin_amdgcn_alignbit(d2, d1, 16);
+        fv[2] = __builtin_amdgcn_alignbit(d3, d2, 16);
+        fv[3] = __builtin_amdgcn_alignbit(d4, d3, 16);
+        const half8 fb = __builtin_bit_cast(half8, fv);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], fb, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][1], fb, acc1, 0, 0, 0);
+      }
+      // ---- epilogue: BN + ReLU, transpose through the wave-private tile, 16-byte stores
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          half4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = h ? acc1[g4 * 4 + e] : acc0[g4 * 4 + e];
+            v[e] = (_Float16)fmaxf(fmaf(a, sc[h][g4][e], sh[h][g4][e]), 0.f);
+          }
+          const int chn = h * 32 + 8 * g4 + 4 * kh;
+          const int chunk = (chn >> 3) ^ (px & 7);
+          *reinterpret_cast<half4*>(etile + px * 128 + (chunk << 4) + ((chn & 4) << 1)) = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int qd = lane + 64 * it;
+        const int pl = qd >> 3, chunk = qd & 7;
+        const int tt = tile * 32 + pl;
+        const half8 v = *reinterpret_cast<const half8*>(etile + pl * 128 + ((chunk ^ (pl & 7)) << 4));
+        if (tt < band_px) {
+          const int oyy = oy0 + tt / p.Wout, oxx = tt % p.Wout;
+          if (oyy < p.Hout)
+            *reinterpret_cast<half8*>(p.Y + (((size_t)b * Hp + oyy + p.pad) * Wp + oxx + p.pad) * 64 + chunk * 8) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+int fp_conv1_nhwc_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int B, int Hin,
+                         int Win, int pad, hipStream_t stream) {
+  Conv1Params p;
+  p.X = (const _Float16*)x; p.W = (const _Float16*)w; p.scale = scale; p.shift = shift; p.Y = (_Float16*)y;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hin / 2; p.Wout = Win / 2; p.pad = pad;
+  p.bands_per_image = fp_cdiv(p.Hout, C1_ROWS);
+  p.total_bands = B * p.bands_per_image;
+  p.PW = Win + 16;
+  const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;
+  const size_t lds = 2 * (size_t)patch_bytes + 4 * 4096;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      fp_set_error("fp_conv7x7s2_bn_relu_fwd: cannot query the device");
+      return FP_ERR_LAUNCH;
+    }
+    n_cu = prop.multiProcessorCount;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv7x7s2_nhwc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if (lds > 160 * 1024) {
+    fp_set_error("fp_conv7x7s2_bn_relu_fwd: input width %d needs %zu bytes of LDS", Win, lds);
+    return FP_ERR_UNSUPPORTED;
+  }
+  const int grid = p.total_bands < n_cu ? p.total_bands : n_cu;
+  hipLaunchKernelGGL(k_conv7x7s2_nhwc, dim3(grid), dim3(C1_THREADS), lds, stream, p);
+  FP_CHECK_LAUNCH("fp_conv7x7s2_bn_relu_fwd(nhwc)");
+  return FP_OK;
+}

@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256) void k_conv7x7s2(const _Float16* __restrict__ 
   }
 }
 
+int fp_conv1_nhwc_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int B, int Hin,
+                         int Win, int pad, hipStream_t stream);   // conv1.hip
+
 extern "C" int fp_conv7x7s2_bn_relu_fwd(const void* x, const void* w, const float* scale, const float* shift, void* y,
                                         int B, int Hin, int Win, int channels_last_out, void* stream) {
   FP_REQUIRE(B >= 0, "fp_conv7x7s2_bn_relu_fwd: B < 0");
@@ -212,6 +215,9 @@ extern "C" int fp_conv7x7s2_bn_relu_fwd(const void* x, const void* w, const floa
   FP_REQUIRE(x && w && scale && shift && y, "fp_conv7x7s2_bn_relu_fwd: NULL tensor");
   FP_REQUIRE(Hin > 0 && Win > 0 && Hin % 2 == 0 && Win % 2 == 0, "fp_conv7x7s2_bn_relu_fwd: odd input size");
   FP_REQUIRE(B <= 65535, "fp_conv7x7s2_bn_relu_fwd: B=%d exceeds the grid limit; chunk the batch", B);
+  FP_REQUIRE(channels_last_out >= 0 && channels_last_out <= 2, "fp_conv7x7s2_bn_relu_fwd: unknown output layout %d", channels_last_out);
+  if (channels_last_out != 0 && Win <= 256 && (Win % 8) == 0)   // NHWC outputs: the streaming kernel of conv1.hip
+    return fp_conv1_nhwc_launch(x, w, scale, shift, y, B, Hin, Win, channels_last_out == 2 ? 1 : 0, (hipStream_t)stream);
   const int Hout = Hin / 2, Wout = Win / 2;
   const int tiles_x = fp_cdiv(Wout, CV_TC), tiles_y = fp_cdiv(Hout, CV_TR);
   hipLaunchKernelGGL(k_conv7x7s2, dim3(tiles_x * tiles_y, B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x,

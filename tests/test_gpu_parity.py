@@ -229,6 +229,18 @@ def test_conv7x7_mfma(dev):
                                   channels_last=cl)
         assert y.shape == (5, 64, 80, 80)
         np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=2e-3)  # fp16 output rounding
+    # NHWC inside a zero-bordered buffer (the layout fp_igemm_f16_fwd consumes); border must stay untouched
+    buf = torch.zeros((5, 82, 82, 64), dtype=torch.float16, device=dev)
+    buf[:, 0] = 7.0
+    ops.conv7x7s2_bn_relu(x16.to(dev), w16.reshape(64, -1).contiguous().to(dev), scale.to(dev), shift.to(dev), out_padded=buf)
+    np.testing.assert_allclose(buf[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=2e-3)
+    assert float((buf[:, 0] - 7.0).abs().max()) == 0 and float(buf[:, -1].abs().max()) == 0 and float(buf[:, :, 0][:, 1:].abs().max()) == 0
+    # ragged shapes: odd number of bands, width not a multiple of 32 pixels per tile
+    x2 = (torch.rand((3, 6, 104, 88), generator=g) * 2 - 1).half()
+    ref2 = torch.relu(torch.nn.functional.conv2d(x2.float(), w16.float(), None, stride=2, padding=3)
+                      * scale[None, :, None, None] + shift[None, :, None, None])
+    y2 = ops.conv7x7s2_bn_relu(x2.to(dev), w16.reshape(64, -1).contiguous().to(dev), scale.to(dev), shift.to(dev), channels_last=True)
+    np.testing.assert_allclose(y2.float().cpu().numpy(), ref2.numpy(), atol=4e-3, rtol=2e-3)
 
 
 @pytest.mark.parametrize("M,K,N", [(800, 512, 1536), (1000, 512, 512), (37, 64, 128)])
