@@ -200,15 +200,18 @@ class _MHA:
         self.out = _Linear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"], dtype, use_hip)
         self.nhead = nhead
 
-    def __call__(self, x, residual=None):
+    def context(self, x):
+        """softmax(q k^T / sqrt(d)) v with heads merged, before the output projection: (Bn, L, D)"""
         Bn, L, D = x.shape
         hd = D // self.nhead
         qkv = self.qkv(x).reshape(Bn, L, 3, self.nhead, hd)
         q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         # fused attention: the (Bn*4, L, L) probability tensor (161 M elements at N=252, which the reference
         # materialises because it calls nn.MultiheadAttention with need_weights=True) never reaches HBM
-        o = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(Bn, L, D)
-        return self.out(o, residual=residual)
+        return F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(Bn, L, D)
+
+    def __call__(self, x, residual=None):
+        return self.out(self.context(x), residual=residual)
 
 
 class _EncoderLayer:
@@ -221,13 +224,25 @@ class _EncoderLayer:
         self.n1 = (sd[p + ".norm1.weight"].float(), sd[p + ".norm1.bias"].float())
         self.n2 = (sd[p + ".norm2.weight"].float(), sd[p + ".norm2.bias"].float())
         self.dtype = dtype
+        self.hip = use_hip and dtype == torch.float16
 
     def _ln(self, x, wb):
+        if self.hip:
+            return ops.layernorm_f16(x, wb[0], wb[1], 1e-5)
         return F.layer_norm(x.float(), (x.shape[-1],), wb[0], wb[1], 1e-5).to(self.dtype)
 
     def __call__(self, x):
         x = self._ln(self.att(x, residual=x), self.n1)
         return self._ln(self.l2(self.l1(x, relu=True), residual=x), self.n2)
+
+    def pooled(self, x):
+        """mean over the tokens of the layer output, (N, L, 512) -> (N, 512) fp32.  On the HIP plan the second
+        LayerNorm is fused with the token mean (fp_colmean_f16_fwd): the normalised tensor is never written."""
+        x = self._ln(self.att(x, residual=x), self.n1)
+        z = self.l2(self.l1(x, relu=True), residual=x)
+        if self.hip:
+            return ops.colmean_f16(z, self.n2[0], self.n2[1], 1e-5)
+        return self._ln(z, self.n2).float().mean(dim=1)
 
 
 def _dev_sd(module_or_sd, device):
@@ -246,13 +261,19 @@ class RefinePlan:
         for name in ("trans", "rot"):
             self.heads[name] = (_EncoderLayer(sd, f"{name}_head.0", self.dtype, use_hip),
                                 sd[f"{name}_head.1.weight"].to(self.dtype), sd[f"{name}_head.1.bias"].to(self.dtype))
+        self.hip = hip
 
     @torch.inference_mode()
     def __call__(self, AB):
         tok = self.enc(AB)
         out = {}
         for name, (layer, w, b) in self.heads.items():
-            out[name] = F.linear(layer(tok), w, b).float().mean(dim=1)
+            if self.hip:
+                # Linear and the token mean commute: mean_t(x_t W^T + b) = (mean_t x_t) W^T + b, so the 512 -> 3|6 head
+                # runs on N rows instead of N*400 (refine_network.py:90-91)
+                out[name] = F.linear(layer.pooled(tok), w.float(), b.float())
+            else:
+                out[name] = F.linear(layer(tok), w, b).float().mean(dim=1)
         return out
 
 
@@ -266,11 +287,17 @@ class ScorePlan:
         self.att = _MHA(sd, "att", self.dtype, use_hip)
         self.att_cross = _MHA(sd, "att_cross", self.dtype, use_hip)
         self.lin_w, self.lin_b = sd["linear.weight"].to(self.dtype), sd["linear.bias"].to(self.dtype)
+        self.hip = hip
 
     @torch.inference_mode()
     def features(self, AB):
         """(2n,6,H,W) -> pooled per-hypothesis features (n,512) (score_network.py:60-74)."""
-        return self.att(self.enc(AB)).float().mean(dim=1).to(self.dtype)
+        tok = self.enc(AB)
+        if self.hip:
+            # out_proj and the token mean commute (score_network.py:73-74): pool the attention output, project N rows
+            pooled = ops.colmean_f16(self.att.context(tok))
+            return F.linear(pooled, self.att.out.w.float(), self.att.out.b32).to(self.dtype)
+        return self.att(tok).float().mean(dim=1).to(self.dtype)
 
     @torch.inference_mode()
     def head(self, feats, L):

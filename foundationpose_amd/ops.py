@@ -286,6 +286,29 @@ def _work_igemm(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, resi
     return by, 2.0 * M * N * Cin * taps
 
 
+def layernorm_f16(x, gamma, beta, eps=1e-5):
+    """LN over the last dim (512) of an fp16 tensor, fp32 statistics -> fp16 (fp_layernorm_f16_fwd)"""
+    x = _dev(x, torch.float16, "x")
+    D = int(x.shape[-1])
+    M = x.numel() // D
+    y = torch.empty_like(x)
+    st = _lib.lib().fp_layernorm_f16_fwd(_ptr(x), _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")),
+                                         float(eps), _ptr(y), M, D, _stream())
+    _lib.check(st, "fp_layernorm_f16_fwd")
+    return y
+
+
+def colmean_f16(x, gamma=None, beta=None, eps=1e-5):
+    """x (G, R, 512) fp16 -> (G, 512) f32: mean over R of LN(x)*gamma+beta (gamma given) or of x (fp_colmean_f16_fwd)"""
+    x = _dev(x, torch.float16, "x")
+    G_, R, D = (int(v) for v in x.shape)
+    out = torch.empty((G_, D), dtype=torch.float32, device=x.device)
+    st = _lib.lib().fp_colmean_f16_fwd(_ptr(x), _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")),
+                                       float(eps), _ptr(out), G_, R, D, _stream())
+    _lib.check(st, "fp_colmean_f16_fwd")
+    return out
+
+
 def cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs):
     """Host op (init-time): returns indices of the kept poses (mycpp.cluster_poses semantics)."""
     P = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 16))
@@ -379,3 +402,5 @@ pose_update = _timed("fp_pose_update", pose_update)
 conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu, _work_conv1)
 linear_f16 = _timed("fp_linear_f16_fwd", linear_f16, _work_linear)
 igemm_f16 = _timed("fp_igemm_f16_fwd", igemm_f16, _work_igemm)
+layernorm_f16 = _timed("fp_layernorm_f16_fwd", layernorm_f16, lambda x, *a, **k: (4.0 * x.numel(), 0.0))
+colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16, lambda x, *a, **k: (2.0 * x.numel(), 0.0))

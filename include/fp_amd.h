@@ -149,6 +149,17 @@ int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/
                      const fp_igemm_geom* r_geom /*host|NULL*/, void* y /*dev*/, const fp_igemm_geom* y_geom /*host*/,
                      int M, int N, int Cin, int taps, int relu, void* stream);
 
+/* The LayerNorms of nn.TransformerEncoderLayer (refine_network.py:56-70; post-norm, eps 1e-5): y = LN(x)*gamma + beta,
+ * x / y (M, D) fp16, statistics in fp32.  D must be 512 (d_model of both networks). */
+int fp_layernorm_f16_fwd(const void* x /*dev*/, const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps,
+                         void* y /*dev*/, int M, int D, void* stream);
+
+/* `.mean(dim=1)` over the tokens of each hypothesis (refine_network.py:90-91, score_network.py:74), optionally fused
+ * with the LayerNorm that precedes it: out[g, :] = mean_{r < rows_per_group} f(x[g*rows_per_group + r, :]) with
+ * f = LN(.)*gamma + beta if gamma != NULL else identity.  x (groups*rows_per_group, D) fp16, out (groups, D) f32. */
+int fp_colmean_f16_fwd(const void* x /*dev*/, const float* gamma /*dev D|NULL*/, const float* beta /*dev D|NULL*/,
+                       float eps, float* out /*dev*/, int groups, int rows_per_group, int D, void* stream);
+
 /* mycpp/src/app/pybind_api.cpp:24-68 cluster_poses (host, init-time). Returns #kept, indices in keep_idx. */
 int fp_cluster_poses(float angle_diff_deg, float dist_diff, const float* poses /*host N,16*/, int N,
                      const float* symmetry_tfs /*host S,16*/, int S, int* keep_idx /*host N*/);

@@ -472,3 +472,45 @@ def test_hip_encoder_matches_torch_fp32_encoder(dev, use_bn):
         (err.max().item(), err.mean().item(), scale)
     # second call reuses the cached zero-bordered buffers: identical result
     assert torch.equal(hip, enc(AB.half().to(dev)))
+
+
+def test_layernorm_and_colmean_kernels(dev):
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = (torch.randn((7, 400, 512), generator=g) * 2 + torch.randn((1, 1, 512), generator=g)).half()
+    gamma, beta = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g) * 0.1
+    ref = torch.nn.functional.layer_norm(x.float(), (512,), gamma, beta, 1e-5)
+    y = ops.layernorm_f16(x.to(dev), gamma.to(dev), beta.to(dev))
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=2e-3)   # fp16 output rounding
+    m = ops.colmean_f16(x.to(dev), gamma.to(dev), beta.to(dev))
+    np.testing.assert_allclose(m.cpu().numpy(), ref.mean(dim=1).numpy(), atol=2e-5, rtol=1e-5)
+    m0 = ops.colmean_f16(x.to(dev))
+    np.testing.assert_allclose(m0.cpu().numpy(), x.float().mean(dim=1).numpy(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(m, ops.colmean_f16(x.to(dev), gamma.to(dev), beta.to(dev)))   # fixed summation order
+
+
+def test_fp16_plans_match_fp32_plans(dev):
+    """deployment plans (HIP encoder, fused LN / token mean, SDPA) vs the fp32 PyTorch plans on the same inputs"""
+    from foundationpose_amd import engine
+    from foundationpose_amd.refine_network import RefineNet
+    from foundationpose_amd.score_network import ScoreNetMultiPair
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    g = torch.Generator(device="cpu").manual_seed(4)
+    n = 6
+    AB = torch.rand((2 * n, 6, 160, 160), generator=g)
+    AB[:, 3:] = AB[:, 3:] * 2 - 1
+    AB = (AB * (torch.rand((2 * n, 1, 160, 160), generator=g) > 0.3)).to(dev)
+    cfg = dict(DEFAULT_REFINE_CFG)
+    net = RefineNet(cfg=cfg, c_in=6)
+    net.load_state_dict(random_state_dict("refine", cfg, 0))
+    o32 = engine.RefinePlan(net, dev, precision="fp32")(AB)
+    o16 = engine.RefinePlan(net, dev, precision="fp16")(AB.half())
+    for k in ("trans", "rot"):
+        assert o16[k].dtype == torch.float32
+        np.testing.assert_allclose(o16[k].cpu().numpy(), o32[k].cpu().numpy(), atol=3e-2 * max(1.0, float(o32[k].abs().max())))
+    cfg = dict(DEFAULT_SCORE_CFG)
+    net = ScoreNetMultiPair(cfg=cfg, c_in=6)
+    net.load_state_dict(random_state_dict("score", cfg, 0))
+    f32 = engine.ScorePlan(net, dev, precision="fp32").features(AB)
+    f16 = engine.ScorePlan(net, dev, precision="fp16").features(AB.half())
+    np.testing.assert_allclose(f16.float().cpu().numpy(), f32.cpu().numpy(), atol=3e-2 * max(1.0, float(f32.abs().max())))
