@@ -24,18 +24,15 @@
 //   * XCD-aware tile order: the channel tiles of one pixel tile run back to back on the same XCD (shared A rows in
 //     that XCD's L2); weights (<= 4.7 MB per layer) stay resident in every L2.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
+#include <string.h>
 #include "fp_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16_ __attribute__((ext_vector_type(16)));
 
-#define IG_BM 128
-#define IG_BN 128
 #define IG_BK 64
-#define IG_THREADS 256
-#define IG_STAGE_BYTES (2 * IG_BM * IG_BK * 2)      // A tile + W tile of one stage = 32 KiB
-#define IG_LDS_BYTES (2 * IG_STAGE_BYTES)            // 64 KiB
 
 struct IgemmGeom {      // row m -> element offset of pixel (b, y*stride + pad_off, x*stride + pad_off) in a padded NHWC buffer
   int HoWo, Wo;         // output pixels per image / per row (1,1 for a plain GEMM)
@@ -70,31 +67,52 @@ __device__ __forceinline__ long long ig_row_off(const IgemmGeom& g, int m) {
          (long long)cg * g.cgroup;
 }
 
-__global__ __launch_bounds__(IG_THREADS, 2) void k_igemm_f16(IgemmParams p) {
+// Workgroup tile BM (pixels) x BN (channels) x 64 (k); every wave owns (32*TM) x 64 outputs as TM x 2
+// v_mfma_f32_32x32x16_f16 tiles; NST LDS stages (prefetch distance NST-1 k-steps, counted vmcnt + raw s_barrier).
+// Measured at the bench shapes: the 2x2-tile variants (128x128x2st, 256x128x3st, ...) all sit at 0.65-0.87 PFLOP/s
+// regardless of prefetch depth -- they are bound by the issue cost of their own LDS-DMA (6-8 global_load_lds per
+// wave against 16 MFMAs per k-step), so the lever is FLOP per staged byte: 4x2 tiles per wave in a 256x256 or
+// 512x128 workgroup tile halve the DMA instructions per MFMA and cut the fragment reads per MFMA by 25 %.
+template <int BM, int BN, int TM, int NST>
+__global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_f16(IgemmParams p) {
+  constexpr int NWN = BN / 64;
+  constexpr int NW = (BM / (32 * TM)) * NWN;
+  constexpr int THREADS = NW * 64;
+  constexpr int A_BYTES = BM * IG_BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + BN * IG_BK * 2;
+  constexpr int AI = BM / 8 / NW;                  // A-tile LDS-DMA instructions per wave and stage
+  constexpr int WI = BN / 8 / NW;                  // W-tile ...
+  constexpr int LPS = AI + WI;
+  constexpr int CPR = BN / 8;                      // 16-byte chunks per row of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;   // wave position: pixels (m) x channels (n)
+  const int wm = wid / NWN, wn = wid - wm * NWN;   // wave position: pixels (m) x channels (n)
 
   // ---- XCD-aware tile order (bijective for any grid size)
-  const int tiles_n = p.N / IG_BN;
+  const int tiles_n = p.N / BN;
   const int nwg = gridDim.x;
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   const int q = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
-  const int m0 = bm * IG_BM, n0 = bn * IG_BN;
+  const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
 
-  // ---- per-thread staging sources: wave w loads rows 32w..32w+31 of both tiles, 4 LDS-DMA instructions each
-  const _Float16* asrc[4];
-  const _Float16* wsrc[4];
+  // ---- per-thread staging sources: wave w loads rows [8*AI*w, +8*AI) of the A tile and [8*WI*w, +8*WI) of the W tile
+  const _Float16* asrc[AI];
+  const _Float16* wsrc[WI];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = wid * 32 + j * 8 + (lane >> 3);
+  for (int j = 0; j < AI; ++j) {
+    const int row = wid * (AI * 8) + j * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);   // logical chunk that lands in physical chunk (lane & 7)
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
     asrc[j] = p.A + ig_row_off(p.in, m) + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    const int row = wid * (WI * 8) + j * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
     wsrc[j] = p.Wt + (size_t)(n0 + row) * Ktot + c * 8;
   }
   const int cpt = p.Cin / IG_BK;            // k-steps per tap
@@ -106,65 +124,85 @@ __global__ __launch_bounds__(IG_THREADS, 2) void k_igemm_f16(IgemmParams p) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const long long aoff = ((long long)ky * p.in.Wp + kx) * p.in.cstride + ci0;   // 0 + ci0 for a plain GEMM (taps = 1)
     const int woff = ks * IG_BK;
-    unsigned char* sa = smem + buf * IG_STAGE_BYTES + wid * 4096;
-    unsigned char* sw = sa + IG_BM * IG_BK * 2;
+    unsigned char* sa = smem + buf * STAGE_BYTES + wid * (AI * 1024);
+    unsigned char* sw = smem + buf * STAGE_BYTES + A_BYTES + wid * (WI * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AI; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + aoff),
                                        (__attribute__((address_space(3))) void*)(sa + j * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + woff),
                                        (__attribute__((address_space(3))) void*)(sw + j * 1024), 16, 0, 0);
-    }
   };
 
-  float16_ acc[2][2];   // [channel tile i][pixel tile j]
+  float16_ acc[2][TM];   // [channel tile i][pixel tile j]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // fragment read addressing: lane reads row (lane & 31), logical chunk 2*kk + (lane >> 5)
   const int frow = lane & 31, fhalf = lane >> 5;
-  int a_rowb[2], w_rowb[2], a_sw[2], w_sw[2];
+  int a_rowb[TM], a_sw[TM], w_rowb[2], w_sw[2];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int ra = wm * (32 * TM) + t * 32 + frow;
+    a_rowb[t] = ra * 128; a_sw[t] = (ra >> 1) & 7;
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int ra = wm * 64 + t * 32 + frow, rw = wn * 64 + t * 32 + frow;
-    a_rowb[t] = ra * 128; a_sw[t] = (ra >> 1) & 7;
+    const int rw = wn * 64 + t * 32 + frow;
     w_rowb[t] = rw * 128; w_sw[t] = (rw >> 1) & 7;
   }
 
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the LDS-DMA of stage 0 has landed
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) stage(s, s);
+  int buf = 0, nbuf = NST - 1;
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) stage(ks + 1, buf ^ 1);
-    const unsigned char* sa = smem + buf * IG_STAGE_BYTES;
-    const unsigned char* sw = sa + IG_BM * IG_BK * 2;
+    // stage ks must have landed; the NST-2 stages issued after it may stay in flight (loads retire in order)
+    if (NST > 2 && ks + NST - 2 < nk) {
+      static_assert(NST <= 2 || LPS * (NST - 2) == 6 || LPS * (NST - 2) == 8, "add the counted wait for this shape");
+      if (LPS * (NST - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();     // everyone's part of stage ks is visible; everyone is done reading stage ks-1
+    if (ks + NST - 1 < nk) stage(ks + NST - 1, nbuf);
+    const unsigned char* sa = smem + buf * STAGE_BYTES;
+    const unsigned char* sw = sa + A_BYTES;
+    // fragment double buffer: the ds_read_b128 of k-substep kk+1 are issued before the MFMAs of kk
+    half8 fa[2][TM], fw[2][2];
+    auto load_frags = [&](int kk, int slot) {
+      const int c = 2 * kk + fhalf;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) fa[slot][t] = *reinterpret_cast<const half8*>(sa + a_rowb[t] + ((c ^ a_sw[t]) << 4));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fw[slot][t] = *reinterpret_cast<const half8*>(sw + w_rowb[t] + ((c ^ w_sw[t]) << 4));
+    };
+    load_frags(0, 0);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int c = 2 * kk + fhalf;
-      half8 fa[2], fw[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fa[t] = *reinterpret_cast<const half8*>(sa + a_rowb[t] + ((c ^ a_sw[t]) << 4));
-        fw[t] = *reinterpret_cast<const half8*>(sw + w_rowb[t] + ((c ^ w_sw[t]) << 4));
-      }
+      if (kk < 3) load_frags(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (hipcc otherwise sinks it below them)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk & 1][i], fa[kk & 1][j], acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
+    buf = (buf + 1 == NST) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
   }
+  __syncthreads();   // all fragment reads done before the staging buffers become the transpose tile
 
   // ---- epilogue: accumulators (+bias) -> half -> swizzled LDS tile E[m][n] -> 16-B coalesced row stores
   // D[i = channel][j = pixel]: lane holds pixel (lane & 31), channels 8g + 4*(lane>>5) + {0..3}, g = reg >> 2
-  unsigned char* E = smem;   // 128 rows x 256 B, chunk index XORed with (m & 15)
+  unsigned char* E = smem;   // BM rows x (2*BN) B, low 4 bits of the chunk index XORed with (m & 15)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -176,24 +214,24 @@ __global__ __launch_bounds__(IG_THREADS, 2) void k_igemm_f16(IgemmParams p) {
         for (int e = 0; e < 4; ++e) bv[e] = p.bias[n0 + nl + e];
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ml = wm * 64 + j * 32 + (lane & 31);
+      for (int j = 0; j < TM; ++j) {
+        const int ml = wm * (32 * TM) + j * 32 + (lane & 31);
         half4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
         const int chunk = (nl >> 3) ^ (ml & 15);
-        *reinterpret_cast<half4*>(E + ml * 256 + (chunk << 4) + ((nl & 4) << 1)) = v;
+        *reinterpret_cast<half4*>(E + ml * (2 * BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
       }
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int qd = tid + it * IG_THREADS;
-    const int ml = qd >> 4, ch = qd & 15;
+  for (int it = 0; it < (BM * CPR) / THREADS; ++it) {
+    const int qd = tid + it * THREADS;
+    const int ml = qd / CPR, ch = qd % CPR;
     const int m = m0 + ml;
     if (m >= p.M) continue;
-    half8 v = *reinterpret_cast<const half8*>(E + ml * 256 + ((ch ^ (ml & 15)) << 4));
+    half8 v = *reinterpret_cast<const half8*>(E + ml * (2 * BN) + ((ch ^ (ml & 15)) << 4));
     const int n = n0 + ch * 8;
     if (p.R) {
       const half8 rv = *reinterpret_cast<const half8*>(p.R + ig_row_off(p.res, m) + n);
@@ -206,6 +244,26 @@ __global__ __launch_bounds__(IG_THREADS, 2) void k_igemm_f16(IgemmParams p) {
     }
     *reinterpret_cast<half8*>(p.Y + ig_row_off(p.out, m) + n) = v;
   }
+}
+
+template <int BM, int BN, int TM, int NST>
+static int ig_launch(const IgemmParams& p, hipStream_t stream) {
+  constexpr int STAGES = NST * (BM + BN) * IG_BK * 2;
+  constexpr int ETILE = BM * BN * 2;
+  constexpr int LDS = STAGES > ETILE ? STAGES : ETILE;
+  constexpr int THREADS = (BM / (32 * TM)) * (BN / 64) * 64;
+  static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+  const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
+  FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_f16<BM, BN, TM, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_igemm_f16<BM, BN, TM, NST>), dim3((unsigned)tiles), dim3(THREADS), LDS, stream, p);
+  FP_CHECK_LAUNCH("fp_igemm_f16_fwd");
+  return FP_OK;
 }
 
 static int ig_check_geom(const fp_igemm_geom* g, const char* what) {
@@ -231,7 +289,7 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   if (M == 0) return FP_OK;
   FP_REQUIRE(x && w && y && x_geom && y_geom, "fp_igemm_f16_fwd: NULL tensor / geometry");
   FP_REQUIRE(taps == 1 || taps == 9, "fp_igemm_f16_fwd: taps must be 1 (GEMM) or 9 (3x3 conv), got %d", taps);
-  FP_REQUIRE(N > 0 && N % IG_BN == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of %d", N, IG_BN);
+  FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
   FP_REQUIRE(Cin > 0 && Cin % IG_BK == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of %d", Cin, IG_BK);
   FP_REQUIRE(!residual || r_geom, "fp_igemm_f16_fwd: residual without geometry");
   if (int e = ig_check_geom(x_geom, "input")) return e;
@@ -241,14 +299,28 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = bias; p.R = (const _Float16*)residual; p.Y = (_Float16*)y;
   p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = relu;
   p.in = ig_geom(x_geom); p.out = ig_geom(y_geom); p.res = residual ? ig_geom(r_geom) : ig_geom(y_geom);
-  const long long tiles = (long long)fp_cdiv(M, IG_BM) * (N / IG_BN);
-  FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_f16), hipFuncAttributeMaxDynamicSharedMemorySize, IG_LDS_BYTES);
-    attr_set = true;
+  // tile selection; FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | 512x128 forces one (profiling aid)
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("FP_IGEMM_TILE");
+    forced = 0;
+    if (e) {
+      if (!strcmp(e, "128x128")) forced = 1;
+      else if (!strcmp(e, "256x128")) forced = 2;
+      else if (!strcmp(e, "256x256")) forced = 3;
+      else if (!strcmp(e, "512x128")) forced = 4;
+    }
   }
-  hipLaunchKernelGGL(k_igemm_f16, dim3((unsigned)tiles), dim3(IG_THREADS), IG_LDS_BYTES, (hipStream_t)stream, p);
-  FP_CHECK_LAUNCH("fp_igemm_f16_fwd");
-  return FP_OK;
+  int sel = forced;
+  // measured at the bench shapes (scripts/bench_igemm.py): 256x256 wins where both M and N are large
+  // (256->256 convs 868 vs 821 TFLOP/s, QKV projection 637 vs 527), 128x128 (two workgroups per CU) elsewhere
+  if (sel == 0) sel = ((N % 256) == 0 && M >= 150000) ? 3 : 1;
+  if (sel == 3 && (N % 256) != 0) sel = 4;
+  switch (sel) {
+    case 1: return ig_launch<128, 128, 2, 2>(p, (hipStream_t)stream);
+    case 2: return ig_launch<256, 128, 2, 3>(p, (hipStream_t)stream);
+    case 3: return ig_launch<256, 256, 4, 2>(p, (hipStream_t)stream);
+    default: return ig_launch<512, 128, 4, 2>(p, (hipStream_t)stream);
+  }
 }
+

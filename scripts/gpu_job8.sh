@@ -1,0 +1,3 @@
+export TMPDIR=/tmp
+for t in 256x256 512x128 128x128; do echo "== $t"; FP_IGEMM_TILE=$t timeout 200 python scripts/bench_igemm.py 2>&1 | grep -E "igemm conv|igemm linear|HipEncoder|RefinePlan"; done
+for t in 256x256 512x128; do echo "== tests $t"; FP_IGEMM_TILE=$t timeout 300 python -m pytest tests -m gpu -x -q -k "igemm or hip_encoder or fp16_plans" 2>&1 | tail -4; done

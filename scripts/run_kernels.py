@@ -22,6 +22,12 @@ sc1, sh1 = torch.ones(64, device=dev), torch.zeros(64, device=dev)
 x = torch.randn((N * 400, 512), generator=g).half().to(dev)
 wq = (torch.randn((1536, 512), generator=g) * 0.05).half().to(dev)
 bq = torch.zeros(1536, device=dev)
+G = ops.IgemmGeom
+xi = (torch.randn((N, 42, 42, 256), generator=g) * 0.5).half().to(dev)
+wi = (torch.randn((256, 9 * 256), generator=g) * 0.02).half().to(dev)
+yi = torch.zeros((N, 42, 42, 256), dtype=torch.float16, device=dev)
+lnw, lnb = torch.ones(512, device=dev), torch.zeros(512, device=dev)
+xt = x.reshape(N, 400, 512)
 for _ in range(reps):
     tf, bb = ops.crop_windows(poses, sc["K"], sc["diameter"], 1.2, (160, 160))
     ops.render_crops(h, poses, bb, sc["K"], 480, 640, (160, 160), sc["diameter"], 0.001, True, A_out=AB[:N])
@@ -29,5 +35,8 @@ for _ in range(reps):
     ops.warp_crops(rgb_t, None, depth_t, tf, sc["K"], poses, sc["diameter"], ops.MODE_SCORE, True, B_out=AB[N:])
     y = ops.conv7x7s2_bn_relu(AB, w1, sc1, sh1, channels_last=True)
     q = ops.linear_f16(x, wq, bq)
+    ops.igemm_f16(xi, G.image(40, 40, 1, 256, offset=0), wi, None, yi, G.image(40, 40, 1, 256), N * 1600, 256, 256, 9, relu=True)
+    ops.layernorm_f16(xt, lnw, lnb)
+    ops.colmean_f16(xt, lnw, lnb)
 torch.cuda.synchronize()
 print("ok")
