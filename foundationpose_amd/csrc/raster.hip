@@ -1,19 +1,10 @@
 // Fused pose-hypothesis rasteriser for gfx950 (replaces nvdiffrast_render, Utils.py:133-219, plus the
 // A-side of make_crop_data_batch / transform_batch / concat -- see include/fp_amd.h).
 //
-// One workgroup = (hypothesis n, strip of SH output rows).  Phases, all inside one launch:
-//   1. vertex pass   : every vertex of the mesh is transformed with pose n, projected into the crop,
-//                      snapped to 1/16 px and cached in LDS as {int16 x, int16 y, f32 1/z} (8 B / vertex)
-//   2. raster pass   : triangle-parallel (one lane per triangle, the typical ~4 px triangle makes a
-//                      pixel-parallel scan of the bin ~10x more work); integer edge functions with a
-//                      top-left tie rule give exact coverage, the depth key
-//                      (round(z_cam * 2^20) << 32 | tri_id) goes into the LDS strip z-buffer with a
-//                      64-bit ds_min -- deterministic winner, independent of arrival order
-//   3. resolve pass  : pixel-parallel, consecutive lanes = consecutive pixels of a row (coalesced stores);
-//                      perspective-correct barycentrics of the winner, attribute interpolation,
-//                      bilinear texture, Lambert shading, (x - t)/radius normalisation, masks, and the
-//                      network tensor A[n, 0:6] is written directly (fp16 or fp32), so no intermediate
-//                      image ever reaches HBM.
+// fp_render_crops = three launches (k_vertex, k_bin, k_raster -- see the pipeline comment below): per-vertex work once
+// per hypothesis, triangles binned to 16-row strips, strip z-buffer in LDS merged with a 64-bit ds_min on the key
+// (round(z_cam * 2^20) << 32 | tri_id) -- deterministic winner, independent of arrival order -- and a pixel-parallel
+// resolve that writes the network tensor A[n, 0:6] directly (fp16 or fp32), so no intermediate image reaches HBM.
 // Compiled with -ffp-contract=off: the float expression order below is the definition shared with the
 // CPU oracle (oracle/fp_oracle.c) and is what makes zbuf / tri_id bit-exact across CPU and GPU.
 #include <hip/hip_fp16.h>
@@ -174,79 +165,219 @@ __device__ __forceinline__ void tex_fetch(const float* __restrict__ tex, int Ht,
   }
 }
 
-// Stand-alone vertex pass for meshes whose vertex cache does not fit in LDS (workspace path).
-__global__ __launch_bounds__(256) void k_vertex_pass(fp_mesh m, const float* __restrict__ poses,
-                                                     const float* __restrict__ bbox2d, fp_k9 K, int H, int W,
-                                                     int oh, int ow, VtxRec* __restrict__ ws) {
+// ---------------------------------------------------------------------------------------------------------------
+// Pipeline of one fp_render_crops call (three launches on the caller's stream, scratch in the caller's workspace):
+//   k_vertex : grid (V/256, N)  one lane per (hypothesis, vertex): camera-space position, unsnapped and snapped crop
+//              position, 1/z, Lambert term of the vertex normal  -> VtxRec (8 B, raster) + VtxAttr (24 B, resolve)
+//   k_bin    : grid (T/256, N)  one lane per (hypothesis, triangle): strips of FP_STRIP_ROWS rows it can touch
+//              -> per-(hypothesis, strip) triangle lists (wave-ballot compaction, one atomicAdd per wave and strip)
+//   k_raster : grid (strips, N) one workgroup per (hypothesis, strip): LDS strip z-buffer
+//              phase 1  lanes walk the strip's triangle list: integer edge functions, 64-bit ds_min of the depth key
+//              phase 2  lanes = pixels (coalesced): barycentrics, interpolation, texture, shading, network tensor A
+// Per-vertex work is done once per hypothesis (not once per strip and not three times per pixel), a strip only ever
+// looks at the triangles binned to it, and 16-row strips (20 KiB of LDS) keep 6-7 workgroups resident per CU.
+#define FP_STRIP_ROWS 16
+#define FP_MAX_STRIPS 64          // oh <= 1024
+#define FP_BIG_CELLS 24           // clipped bounding boxes above this many pixels are rasterised cooperatively
+#define FP_BIG_MAX 96             // queue capacity (entries of 56 B)
+
+struct VtxAttr {            // per (hypothesis, vertex), resolve-side
+  float xc, yc, zc;        // camera-space position
+  float X, Y;              // unsnapped crop-pixel position
+  float dk;                // clip(normalize(R n) . (0,0,-1), 0, 1)  (Utils.py:203-206)
+};
+
+struct BigTri {             // a finished triangle setup parked in LDS (oriented: area2 > 0)
+  int x0, y0, x1, y1, x2, y2;
+  float iw0, iw1, iw2;
+  int t, i0, i1, j0, j1;
+};
+
+struct RenderWs {
+  VtxRec* vr;              // [N][V]
+  VtxAttr* va;             // [N][V]
+  int* counts;             // [N][strips]
+  unsigned short* lists16; // [N][strips][T]   (T <= 65535)
+  int* lists32;            // same with 32-bit ids for larger meshes
+};
+
+__global__ __launch_bounds__(256) void k_vertex(fp_mesh m, const float* __restrict__ poses,
+                                                const float* __restrict__ bbox2d, fp_k9 K, int H, int W, int oh, int ow,
+                                                int nstrips, RenderWs ws) {
   const int n = blockIdx.y;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < nstrips) ws.counts[n * nstrips + threadIdx.x] = 0;
   if (v >= m.V) return;
   const HypConst h = load_hyp(poses, bbox2d, K, n, H, W, oh, ow);
-  ws[(size_t)n * m.V + v] = project_vertex(h, m.pos[v * 3], m.pos[v * 3 + 1], m.pos[v * 3 + 2]);
+  const float vx = m.pos[v * 3], vy = m.pos[v * 3 + 1], vz = m.pos[v * 3 + 2];
+  VtxAttr a;
+  cam_point(h, vx, vy, vz, a.xc, a.yc, a.zc);
+  crop_xy(h, a.xc, a.yc, a.zc, a.X, a.Y);
+  const float* vn = m.nrm + (size_t)v * 3;
+  const float n0 = fmaf(h.P[2], vn[2], fmaf(h.P[1], vn[1], h.P[0] * vn[0]));
+  const float n1 = fmaf(h.P[6], vn[2], fmaf(h.P[5], vn[1], h.P[4] * vn[0]));
+  const float n2 = fmaf(h.P[10], vn[2], fmaf(h.P[9], vn[1], h.P[8] * vn[0]));
+  const float len = sqrtf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)));
+  a.dk = clamp01((-n2) / fmaxf(len, 1e-12f));
+  const size_t o = (size_t)n * m.V + v;
+  ws.va[o] = a;
+  ws.vr[o] = project_vertex(h, vx, vy, vz);
 }
 
-template <bool VLDS>
-__global__ __launch_bounds__(FP_RASTER_THREADS) void k_render(
-    fp_mesh m, const float* __restrict__ poses, const float* __restrict__ bbox2d, fp_k9 K, int H, int W, int oh,
-    int ow, int SH, float w_ambient, float w_diffuse, float inv_r, float xyz_thr, int flags, RenderOut out,
-    const VtxRec* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__global__ __launch_bounds__(256) void k_bin(fp_mesh m, int oh, int ow, int nstrips, RenderWs ws) {
   const int n = blockIdx.y;
-  const int row0 = blockIdx.x * SH;
-  const int rows = min(SH, oh - row0);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int s0 = 1, s1 = 0;   // empty range
+  if (t < m.T) {
+    const VtxRec* vr = ws.vr + (size_t)n * m.V;
+    const VtxRec r0 = vr[m.faces[t * 3]], r1 = vr[m.faces[t * 3 + 1]], r2 = vr[m.faces[t * 3 + 2]];
+    TriSetup tr;
+    if (tri_setup(r0, r1, r2, tr)) {
+      const int miny = min(tr.y0, min(tr.y1, tr.y2)), maxy = max(tr.y0, max(tr.y1, tr.y2));
+      const int minx = min(tr.x0, min(tr.x1, tr.x2)), maxx = max(tr.x0, max(tr.x1, tr.x2));
+      const int i0 = max((minx - 8 + 15) >> 4, 0), i1 = min((maxx - 8) >> 4, ow - 1);
+      const int j0 = max((miny - 8 + 15) >> 4, 0), j1 = min((maxy - 8) >> 4, oh - 1);
+      if (i0 <= i1 && j0 <= j1) { s0 = j0 / FP_STRIP_ROWS; s1 = j1 / FP_STRIP_ROWS; }
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  // strips any lane of this wave touches
+  int lo = s0 <= s1 ? s0 : FP_MAX_STRIPS, hi = s0 <= s1 ? s1 : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+  // lane s keeps the ballot of strip s, so the (up to 64) atomicAdds of a wave are all in flight together
+  unsigned long long mymask = 0ull;
+  for (int s = lo; s <= hi; ++s) {
+    const unsigned long long mask = __ballot(s >= s0 && s <= s1);
+    if (lane == s) mymask = mask;
+  }
+  int mybase = 0;
+  if (mymask != 0ull) mybase = atomicAdd(&ws.counts[n * nstrips + lane], __popcll(mymask));
+  for (int s = lo; s <= hi; ++s) {
+    const unsigned long long mask = __shfl(mymask, s, 64);
+    const int base = __shfl(mybase, s, 64);
+    if (s >= s0 && s <= s1) {
+      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      const size_t li = ((size_t)n * nstrips + s) * m.T + pos;
+      if (ws.lists16) ws.lists16[li] = (unsigned short)t;
+      else ws.lists32[li] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
+    fp_mesh m, const float* __restrict__ poses, const float* __restrict__ bbox2d, fp_k9 K, int H, int W, int oh,
+    int ow, int nstrips, float w_ambient, float w_diffuse, float inv_r, float xyz_thr, int flags, RenderOut out,
+    RenderWs ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = blockIdx.y, strip = blockIdx.x;
+  const int row0 = strip * FP_STRIP_ROWS;
+  const int rows = min(FP_STRIP_ROWS, oh - row0);
   const int npix = rows * ow;
   unsigned long long* zb = reinterpret_cast<unsigned long long*>(smem);
-  VtxRec* vc = reinterpret_cast<VtxRec*>(smem + (size_t)SH * ow * sizeof(unsigned long long));
+  int* nbig = reinterpret_cast<int*>(smem + (size_t)FP_STRIP_ROWS * ow * sizeof(unsigned long long));
+  BigTri* big = reinterpret_cast<BigTri*>(nbig + 4);
   const int tid = threadIdx.x;
-  const HypConst h = load_hyp(poses, bbox2d, K, n, H, W, oh, ow);
+  if (tid == 0) *nbig = 0;
+  const VtxRec* vr = ws.vr + (size_t)n * m.V;
+  const VtxAttr* va = ws.va + (size_t)n * m.V;
 
-  // ---- phase 1: vertex cache + z-buffer clear
-  if (VLDS) {
-    for (int v = tid; v < m.V; v += FP_RASTER_THREADS)
-      vc[v] = project_vertex(h, m.pos[v * 3], m.pos[v * 3 + 1], m.pos[v * 3 + 2]);
-  }
-  const VtxRec* vsrc = VLDS ? vc : (ws + (size_t)n * m.V);
   for (int p = tid; p < npix; p += FP_RASTER_THREADS) zb[p] = FP_KEY_EMPTY;
   __syncthreads();
 
-  // ---- phase 2: triangle-parallel raster into the LDS strip
-  const int ylo = row0 * 16 + 8;                 // sub-pixel y of the first / last pixel centre of this strip
-  const int yhi = (row0 + rows - 1) * 16 + 8;
-  for (int t = tid; t < m.T; t += FP_RASTER_THREADS) {
-    const int f0 = m.faces[t * 3], f1 = m.faces[t * 3 + 1], f2 = m.faces[t * 3 + 2];
-    const VtxRec r0 = vsrc[f0], r1 = vsrc[f1], r2 = vsrc[f2];
-    TriSetup tr;
-    if (!tri_setup(r0, r1, r2, tr)) continue;
-    const int miny = min(tr.y0, min(tr.y1, tr.y2)), maxy = max(tr.y0, max(tr.y1, tr.y2));
-    if (maxy < ylo || miny > yhi) continue;
-    const int minx = min(tr.x0, min(tr.x1, tr.x2)), maxx = max(tr.x0, max(tr.x1, tr.x2));
-    int i0 = (minx - 8 + 15) >> 4, i1 = (maxx - 8) >> 4;
-    int j0 = (miny - 8 + 15) >> 4, j1 = (maxy - 8) >> 4;
-    i0 = max(i0, 0); i1 = min(i1, ow - 1);
-    j0 = max(j0, row0); j1 = min(j1, row0 + rows - 1);
-    if (i0 > i1 || j0 > j1) continue;
-    const float iw0 = r0.iw;
-    const float iw1 = (tr.s1 == 1) ? r1.iw : r2.iw;
-    const float iw2 = (tr.s1 == 1) ? r2.iw : r1.iw;
+  // ---- phase 1: the strip's triangle list -> LDS z-buffer.  One lane per triangle; a triangle whose clipped bounding
+  // box exceeds FP_BIG_CELLS pixels (the fan triangles of a cap span 50 x 16 of them) would stall its whole wave in
+  // the per-lane pixel loop, so it is queued and rasterised afterwards by all lanes together (pixel-parallel).
+  const int cnt = (flags & 0x20000) ? 0 : ws.counts[n * nstrips + strip];   // 0x20000: profiling aid, skip phase 1
+  const size_t lbase = ((size_t)n * nstrips + strip) * m.T;
+  // edge functions are affine in the pixel index: w_k(i+1, j) = w_k(i, j) + 16*dwx_k, so a row costs three integer adds
+  // per cell after one evaluation at its first cell (`first`/`step` stride the cells of a row-major walk over lanes)
+  auto raster_cells = [&](const TriSetup& tr, float iw0, float iw1, float iw2, int t, int i0, int i1, int j0, int j1,
+                          int first, int step) {
+    if (flags & 0x40000) return;   // profiling aid: setup only
     const float fE = (float)tr.area2;
-    for (int j = j0; j <= j1; ++j) {
-      for (int i = i0; i <= i1; ++i) {
+    const int dx0 = -16 * (tr.y2 - tr.y1), dx1 = -16 * (tr.y0 - tr.y2), dx2 = -16 * (tr.y1 - tr.y0);
+    auto cell = [&](int i, int j, int w0, int w1, int w2) {
+      if (((w0 + tr.b0) | (w1 + tr.b1) | (w2 + tr.b2)) < 0) return;
+      const float g0 = (float)w0, g1 = (float)w1, g2 = (float)w2;
+      const float S = fmaf(g2, iw2, fmaf(g1, iw1, g0 * iw0));
+      const float z = fE / S;
+      const float zc = fminf(z, FP_ZMAXF);
+      const uint32_t zq = (uint32_t)rintf(zc * FP_ZSCALEF);
+      const unsigned long long key = ((unsigned long long)zq << 32) | (uint32_t)t;
+      if (flags & 0x80000) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32))); }   // profiling aid: no LDS atomic
+      else atomicMin(&zb[(j - row0) * ow + i], key);
+    };
+    if (step == 1) {            // one lane owns the whole box: incremental walk
+      for (int j = j0; j <= j1; ++j) {
+        int w0, w1, w2;
+        tri_weights(tr, 16 * i0 + 8, 16 * j + 8, w0, w1, w2);
+        for (int i = i0; i <= i1; ++i) {
+          cell(i, j, w0, w1, w2);
+          w0 += dx0; w1 += dx1; w2 += dx2;
+        }
+      }
+    } else {                    // the lanes of a wave stride the cells of the box
+      const int bw = i1 - i0 + 1;
+      const int cells = bw * (j1 - j0 + 1);
+      for (int c = first; c < cells; c += step) {
+        const int jj = c / bw, i = i0 + (c - jj * bw), j = j0 + jj;
         int w0, w1, w2;
         tri_weights(tr, 16 * i + 8, 16 * j + 8, w0, w1, w2);
-        if (((w0 + tr.b0) | (w1 + tr.b1) | (w2 + tr.b2)) < 0) continue;
-        const float g0 = (float)w0, g1 = (float)w1, g2 = (float)w2;
-        const float S = fmaf(g2, iw2, fmaf(g1, iw1, g0 * iw0));
-        const float z = fE / S;
-        const float zc = fminf(z, FP_ZMAXF);
-        const uint32_t zq = (uint32_t)rintf(zc * FP_ZSCALEF);
-        const unsigned long long key = ((unsigned long long)zq << 32) | (uint32_t)t;
-        atomicMin(&zb[(j - row0) * ow + i], key);
+        cell(i, j, w0, w1, w2);
       }
+    }
+  };
+  auto setup = [&](int t, TriSetup& tr, float& iw0, float& iw1, float& iw2, int& i0, int& i1, int& j0, int& j1) -> bool {
+    const VtxRec r0 = vr[m.faces[t * 3]], r1 = vr[m.faces[t * 3 + 1]], r2 = vr[m.faces[t * 3 + 2]];
+    if (!tri_setup(r0, r1, r2, tr)) return false;
+    const int miny = min(tr.y0, min(tr.y1, tr.y2)), maxy = max(tr.y0, max(tr.y1, tr.y2));
+    const int minx = min(tr.x0, min(tr.x1, tr.x2)), maxx = max(tr.x0, max(tr.x1, tr.x2));
+    i0 = max((minx - 8 + 15) >> 4, 0); i1 = min((maxx - 8) >> 4, ow - 1);
+    j0 = max((miny - 8 + 15) >> 4, row0); j1 = min((maxy - 8) >> 4, row0 + rows - 1);
+    iw0 = r0.iw;
+    iw1 = (tr.s1 == 1) ? r1.iw : r2.iw;
+    iw2 = (tr.s1 == 1) ? r2.iw : r1.iw;
+    return i0 <= i1 && j0 <= j1;
+  };
+  for (int e = tid; e < cnt; e += FP_RASTER_THREADS) {
+    const int t = ws.lists16 ? (int)ws.lists16[lbase + e] : ws.lists32[lbase + e];
+    TriSetup tr;
+    float iw0, iw1, iw2;
+    int i0, i1, j0, j1;
+    if (!setup(t, tr, iw0, iw1, iw2, i0, i1, j0, j1)) continue;
+    if ((i1 - i0 + 1) * (j1 - j0 + 1) > FP_BIG_CELLS) {
+      const int slot = atomicAdd(nbig, 1);
+      if (slot < FP_BIG_MAX) {   // park the finished setup in LDS; queue full: fall through to the per-lane loop
+        BigTri& b = big[slot];
+        b.x0 = tr.x0; b.y0 = tr.y0; b.x1 = tr.x1; b.y1 = tr.y1; b.x2 = tr.x2; b.y2 = tr.y2;
+        b.iw0 = iw0; b.iw1 = iw1; b.iw2 = iw2; b.t = t; b.i0 = i0; b.i1 = i1; b.j0 = j0; b.j1 = j1;
+        continue;
+      }
+    }
+    raster_cells(tr, iw0, iw1, iw2, t, i0, i1, j0, j1, 0, 1);
+  }
+  __syncthreads();
+  {
+    // one wave per parked triangle, its 64 lanes over the clipped bounding box
+    const int nb = min(*nbig, FP_BIG_MAX);
+    const int lane = tid & 63;
+    for (int q = tid >> 6; q < nb; q += FP_RASTER_THREADS / 64) {
+      const BigTri b = big[q];
+      TriSetup tr;
+      tr.x0 = b.x0; tr.y0 = b.y0; tr.x1 = b.x1; tr.y1 = b.y1; tr.x2 = b.x2; tr.y2 = b.y2;
+      tr.area2 = (b.x1 - b.x0) * (b.y2 - b.y0) - (b.y1 - b.y0) * (b.x2 - b.x0);   // already oriented: > 0
+      tr.b0 = edge_owner(tr.x2 - tr.x1, tr.y2 - tr.y1) ? 0 : -1;
+      tr.b1 = edge_owner(tr.x0 - tr.x2, tr.y0 - tr.y2) ? 0 : -1;
+      tr.b2 = edge_owner(tr.x1 - tr.x0, tr.y1 - tr.y0) ? 0 : -1;
+      tr.s1 = 1; tr.s2 = 2;
+      raster_cells(tr, b.iw0, b.iw1, b.iw2, b.t, b.i0, b.i1, b.j0, b.j1, lane, 64);
     }
   }
   __syncthreads();
 
-  // ---- phase 3: resolve + shade + write
+  // ---- phase 2: resolve + shade + write
+  const HypConst h = load_hyp(poses, bbox2d, K, n, H, W, oh, ow);
   const size_t plane = (size_t)oh * ow;
   const float t0 = h.P[3], t1 = h.P[7], t2 = h.P[11];
   const bool normalize = (flags & FP_FLAG_NORMALIZE_XYZ) != 0;
@@ -257,31 +388,25 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_render(
     const bool covered = key != FP_KEY_EMPTY;
     float col[3] = {0.f, 0.f, 0.f}, pt[3] = {0.f, 0.f, 0.f}, nm[3] = {0.f, 0.f, 0.f};
     int tid_out = -1;
-    if (covered) {
+    if (covered && !(flags & 0x10000)) {   // 0x10000: profiling aid, skip the shading gathers
       const int t = (int)(uint32_t)(key & 0xFFFFFFFFull);
       tid_out = t;
-      const int f[3] = {m.faces[t * 3], m.faces[t * 3 + 1], m.faces[t * 3 + 2]};
+      const int fa0 = m.faces[t * 3], fa1 = m.faces[t * 3 + 1], fa2 = m.faces[t * 3 + 2];
+      const VtxAttr A0 = va[fa0], A1 = va[fa1], A2 = va[fa2];
       // nvdiffrast's per-pixel pass: perspective-correct barycentrics of the winner from its
       // UNSNAPPED vertices in face order, p_k = z_k * (X_k - pixel centre), a0 = p1 x p2, ..., clamped (u, v), 1-u-v
-      const int fa0 = f[0], fa1 = f[1], fa2 = f[2];
-      float q0[3], q1[3], q2[3], X0, Y0, X1, Y1, X2, Y2;
-      cam_point(h, m.pos[fa0 * 3], m.pos[fa0 * 3 + 1], m.pos[fa0 * 3 + 2], q0[0], q0[1], q0[2]);
-      cam_point(h, m.pos[fa1 * 3], m.pos[fa1 * 3 + 1], m.pos[fa1 * 3 + 2], q1[0], q1[1], q1[2]);
-      cam_point(h, m.pos[fa2 * 3], m.pos[fa2 * 3 + 1], m.pos[fa2 * 3 + 2], q2[0], q2[1], q2[2]);
-      crop_xy(h, q0[0], q0[1], q0[2], X0, Y0);
-      crop_xy(h, q1[0], q1[1], q1[2], X1, Y1);
-      crop_xy(h, q2[0], q2[1], q2[2], X2, Y2);
       const float fxp = (float)i + 0.5f, fyp = (float)j + 0.5f;
-      const float p0x = (X0 - fxp) * q0[2], p0y = (Y0 - fyp) * q0[2];
-      const float p1x = (X1 - fxp) * q1[2], p1y = (Y1 - fyp) * q1[2];
-      const float p2x = (X2 - fxp) * q2[2], p2y = (Y2 - fyp) * q2[2];
+      const float p0x = (A0.X - fxp) * A0.zc, p0y = (A0.Y - fyp) * A0.zc;
+      const float p1x = (A1.X - fxp) * A1.zc, p1y = (A1.Y - fyp) * A1.zc;
+      const float p2x = (A2.X - fxp) * A2.zc, p2y = (A2.Y - fyp) * A2.zc;
       const float m0a = p1x * p2y, m0b = p1y * p2x, m1a = p2x * p0y, m1b = p2y * p0x, m2a = p0x * p1y, m2b = p0y * p1x;
       const float a0 = m0a - m0b, a1 = m1a - m1b, a2 = m2a - m2b;
       const float iwb = 1.0f / ((a0 + a1) + a2);
       const float b0 = clamp01(a0 * iwb), b1 = clamp01(a1 * iwb);
       const float b2 = (1.0f - b0) - b1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) pt[c] = fmaf(b2, q2[c], fmaf(b1, q1[c], b0 * q0[c]));
+      pt[0] = fmaf(b2, A2.xc, fmaf(b1, A1.xc, b0 * A0.xc));
+      pt[1] = fmaf(b2, A2.yc, fmaf(b1, A1.yc, b0 * A0.yc));
+      pt[2] = fmaf(b2, A2.zc, fmaf(b1, A1.zc, b0 * A0.zc));
       float base[3];
       if (m.tex) {
         const int32_t* fu = (m.uv_idx ? m.uv_idx : m.faces) + (size_t)t * 3;
@@ -296,26 +421,26 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_render(
         for (int c = 0; c < 3; ++c)
           base[c] = fmaf(b2, m.vcol[fa2 * 3 + c], fmaf(b1, m.vcol[fa1 * 3 + c], b0 * m.vcol[fa0 * 3 + c]));
       }
-      const int fav[3] = {fa0, fa1, fa2};
-      const float bb[3] = {b0, b1, b2};
-      float nk[3][3], dk[3];
+      const float dsum = fmaf(b2, A2.dk, fmaf(b1, A1.dk, b0 * A0.dk));
+      if (out.normal) {   // only the nvdiffrast_render shim asks for normals: redo the per-vertex transform here
+        const int fav[3] = {fa0, fa1, fa2};
+        const float bb[3] = {b0, b1, b2};
+        float nk[3][3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float* vn = m.nrm + (size_t)fav[k] * 3;
-        nk[k][0] = fmaf(h.P[2], vn[2], fmaf(h.P[1], vn[1], h.P[0] * vn[0]));
-        nk[k][1] = fmaf(h.P[6], vn[2], fmaf(h.P[5], vn[1], h.P[4] * vn[0]));
-        nk[k][2] = fmaf(h.P[10], vn[2], fmaf(h.P[9], vn[1], h.P[8] * vn[0]));
-        const float len = sqrtf(fmaf(nk[k][2], nk[k][2], fmaf(nk[k][1], nk[k][1], nk[k][0] * nk[k][0])));
-        dk[k] = clamp01((-nk[k][2]) / fmaxf(len, 1e-12f));
+        for (int k = 0; k < 3; ++k) {
+          const float* vn = m.nrm + (size_t)fav[k] * 3;
+          nk[k][0] = fmaf(h.P[2], vn[2], fmaf(h.P[1], vn[1], h.P[0] * vn[0]));
+          nk[k][1] = fmaf(h.P[6], vn[2], fmaf(h.P[5], vn[1], h.P[4] * vn[0]));
+          nk[k][2] = fmaf(h.P[10], vn[2], fmaf(h.P[9], vn[1], h.P[8] * vn[0]));
+        }
+        float nsum[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nsum[c] = fmaf(bb[2], nk[2][c], fmaf(bb[1], nk[1][c], bb[0] * nk[0][c]));
+        const float nl = sqrtf(fmaf(nsum[2], nsum[2], fmaf(nsum[1], nsum[1], nsum[0] * nsum[0])));
+        const float inl = fmaxf(nl, 1e-12f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nm[c] = nsum[c] / inl;
       }
-      float nsum[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) nsum[c] = fmaf(bb[2], nk[2][c], fmaf(bb[1], nk[1][c], bb[0] * nk[0][c]));
-      const float dsum = fmaf(bb[2], dk[2], fmaf(bb[1], dk[1], bb[0] * dk[0]));
-      const float nl = sqrtf(fmaf(nsum[2], nsum[2], fmaf(nsum[1], nsum[1], nsum[0] * nsum[0])));
-      const float inl = fmaxf(nl, 1e-12f);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) nm[c] = nsum[c] / inl;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float amb = base[c] * w_ambient;
@@ -360,26 +485,27 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_render(
 }
 
 // ---------------------------------------------------------------- host side
-#define FP_LDS_BUDGET (160 * 1024)
-#define FP_ZB_TARGET (40 * 160 * 8)   // 50 KiB strip z-buffer => 2-3 workgroups per CU
+static inline size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int strip_rows(int oh, int ow) {
-  int sh = FP_ZB_TARGET / (ow * 8);
-  if (sh < 1) sh = 1;
-  if (sh > oh) sh = oh;
-  return sh;
-}
+struct WsLayout { size_t vr, va, counts, lists, total; int nstrips; bool ids16; };
 
-static bool vertex_cache_in_lds(int V, int oh, int ow) {
-  const size_t zb = (size_t)strip_rows(oh, ow) * ow * 8;
-  return zb + (size_t)V * sizeof(VtxRec) <= 80 * 1024;  // keep two workgroups per CU resident
+static WsLayout ws_layout(int N, int V, int T, int oh) {
+  WsLayout L;
+  L.nstrips = fp_cdiv(oh, FP_STRIP_ROWS);
+  L.ids16 = T <= 65535;
+  size_t o = 0;
+  L.vr = o; o = ws_align(o + (size_t)N * V * sizeof(VtxRec));
+  L.va = o; o = ws_align(o + (size_t)N * V * sizeof(VtxAttr));
+  L.counts = o; o = ws_align(o + (size_t)N * L.nstrips * sizeof(int));
+  L.lists = o; o = ws_align(o + (size_t)N * L.nstrips * T * (L.ids16 ? 2 : 4));
+  L.total = o;
+  return L;
 }
 
 extern "C" size_t fp_workspace_bytes(int N, int V, int T, int oh, int ow) {
-  (void)T;
-  if (N <= 0 || V <= 0) return 0;
-  if (vertex_cache_in_lds(V, oh, ow)) return 0;
-  return (size_t)N * V * sizeof(VtxRec);
+  (void)ow;
+  if (N <= 0 || V <= 0 || T <= 0 || oh <= 0) return 0;
+  return ws_layout(N, V, T, oh).total;
 }
 
 extern "C" int fp_render_crops(const fp_mesh* mesh, const float* poses, const float* bbox2d, const float* K9, int H,
@@ -393,41 +519,34 @@ extern "C" int fp_render_crops(const fp_mesh* mesh, const float* poses, const fl
   FP_REQUIRE(oh > 0 && ow > 0 && oh <= 1024 && ow <= 1024, "fp_render_crops: output size %dx%d unsupported (max 1024)", oh, ow);
   FP_REQUIRE(bbox2d || (oh == H && ow == W), "fp_render_crops: full-frame render needs oh==H and ow==W");
   FP_REQUIRE(N <= 65535, "fp_render_crops: N=%d exceeds the grid limit; chunk the batch", N);
+  const WsLayout L = ws_layout(N, mesh->V, mesh->T, oh);
+  if (!workspace || workspace_bytes < L.total) {
+    fp_set_error("fp_render_crops: workspace too small (%zu < %zu bytes, see fp_workspace_bytes)", workspace_bytes, L.total);
+    return FP_ERR_WORKSPACE;
+  }
   fp_k9 K;
   for (int i = 0; i < 9; ++i) K.v[i] = K9[i];
-  const int SH = strip_rows(oh, ow);
-  const int nstrips = fp_cdiv(oh, SH);
-  const bool vlds = vertex_cache_in_lds(mesh->V, oh, ow);
+  unsigned char* w8 = (unsigned char*)workspace;
+  RenderWs ws;
+  ws.vr = (VtxRec*)(w8 + L.vr); ws.va = (VtxAttr*)(w8 + L.va); ws.counts = (int*)(w8 + L.counts);
+  ws.lists16 = L.ids16 ? (unsigned short*)(w8 + L.lists) : nullptr;
+  ws.lists32 = L.ids16 ? nullptr : (int*)(w8 + L.lists);
   const float inv_r = 1.0f / (mesh_diameter * 0.5f);
   RenderOut out = {A, color, depth, xyz, normal, zbuf, tri_id};
   hipStream_t st = (hipStream_t)stream;
-  size_t lds = (size_t)SH * ow * 8;
-  if (vlds) {
-    lds += (size_t)mesh->V * sizeof(VtxRec);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FP_LDS_BUDGET);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(k_render<true>, dim3(nstrips, N), dim3(FP_RASTER_THREADS), lds, st, *mesh, poses, bbox2d, K, H,
-                       W, oh, ow, SH, w_ambient, w_diffuse, inv_r, xyz_thr, flags, out, (const VtxRec*)nullptr);
-  } else {
-    const size_t need = (size_t)N * mesh->V * sizeof(VtxRec);
-    if (!workspace || workspace_bytes < need) {
-      fp_set_error("fp_render_crops: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-      return FP_ERR_WORKSPACE;
-    }
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FP_LDS_BUDGET);
-      attr_set2 = true;
-    }
-    hipLaunchKernelGGL(k_vertex_pass, dim3(fp_cdiv(mesh->V, 256), N), dim3(256), 0, st, *mesh, poses, bbox2d, K, H, W,
-                       oh, ow, (VtxRec*)workspace);
-    FP_CHECK_LAUNCH("fp_render_crops(vertex pass)");
-    hipLaunchKernelGGL(k_render<false>, dim3(nstrips, N), dim3(FP_RASTER_THREADS), lds, st, *mesh, poses, bbox2d, K, H,
-                       W, oh, ow, SH, w_ambient, w_diffuse, inv_r, xyz_thr, flags, out, (const VtxRec*)workspace);
+  hipLaunchKernelGGL(k_vertex, dim3(fp_cdiv(mesh->V, 256), N), dim3(256), 0, st, *mesh, poses, bbox2d, K, H, W, oh, ow,
+                     L.nstrips, ws);
+  FP_CHECK_LAUNCH("fp_render_crops(vertex)");
+  hipLaunchKernelGGL(k_bin, dim3(fp_cdiv(mesh->T, 256), N), dim3(256), 0, st, *mesh, oh, ow, L.nstrips, ws);
+  FP_CHECK_LAUNCH("fp_render_crops(bin)");
+  const size_t lds = (size_t)FP_STRIP_ROWS * ow * sizeof(unsigned long long) + 16 + FP_BIG_MAX * sizeof(BigTri);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_raster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
   }
+  hipLaunchKernelGGL(k_raster, dim3(L.nstrips, N), dim3(FP_RASTER_THREADS), lds, st, *mesh, poses, bbox2d, K, H, W, oh, ow,
+                     L.nstrips, w_ambient, w_diffuse, inv_r, xyz_thr, flags, out, ws);
   FP_CHECK_LAUNCH("fp_render_crops");
   return FP_OK;
 }

@@ -32,8 +32,17 @@ def test_argument_errors_are_reported_without_gpu():
     assert st == -1 and b"fp_mesh_create" in lib.fp_last_error()
     assert lib.fp_linear_f16_fwd(C.c_void_p(8), C.c_void_p(8), None, C.c_void_p(8), 4, 33, 128, 0, None) == -1
     assert b"multiple" in lib.fp_last_error()
-    assert lib.fp_workspace_bytes(252, 2501, 4900, 160, 160) == 0          # vertex cache lives in LDS
-    assert lib.fp_workspace_bytes(4, 100000, 200000, 160, 160) == 4 * 100000 * 8
+    # scratch = per-hypothesis vertex records (32 B / vertex) + per-strip triangle lists (10 strips of 16 rows)
+    ws = lib.fp_workspace_bytes(252, 2501, 4900, 160, 160)
+    assert 252 * (2501 * 32 + 10 * 4900 * 2) <= ws <= 252 * (2501 * 32 + 10 * 4900 * 2) + 4096
+    assert lib.fp_workspace_bytes(0, 2501, 4900, 160, 160) == 0
+    big = lib.fp_workspace_bytes(4, 100000, 200000, 160, 160)        # > 65535 triangles: 32-bit ids in the lists
+    assert big >= 4 * (100000 * 32 + 10 * 200000 * 4)
+    # GEMM geometry errors
+    G = (C.c_int * 10)(1, 1, 1, 1, 1, 0, 512, 0, 0, 0)
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(8), G, C.c_void_p(8), None, None, None, C.c_void_p(8), G, 4, 100, 512, 1, 0, None) == -1
+    assert b"multiple of 128" in lib.fp_last_error()
+    assert lib.fp_layernorm_f16_fwd(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1e-5, C.c_void_p(8), 4, 256, None) == -1
 
 
 def test_product_does_not_import_oracle():

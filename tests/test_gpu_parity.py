@@ -158,7 +158,7 @@ def test_render_degenerate_inputs(scene, dev, gmesh):
 
 
 def test_render_large_mesh_workspace_path(scene, dev):
-    """V > LDS vertex-cache capacity => vertex pass through the HBM workspace; same bits as the oracle"""
+    """large mesh (25,920 triangles, 13k vertices): long per-strip lists; same bits as the oracle"""
     from foundationpose_amd import ops
     from foundationpose_amd.mesh import make_can_mesh
     from foundationpose_amd.Utils import make_mesh_tensors
