@@ -34,7 +34,7 @@ def test_argument_errors_are_reported_without_gpu():
     assert b"multiple" in lib.fp_last_error()
     # scratch = per-hypothesis vertex records (32 B / vertex) + per-strip triangle lists (10 strips of 16 rows)
     ws = lib.fp_workspace_bytes(252, 2501, 4900, 160, 160)
-    assert 252 * (2501 * 32 + 10 * 4900 * 2) <= ws <= 252 * (2501 * 32 + 10 * 4900 * 2) + 4096
+    assert 252 * (2501 * 32 + 10 * 4900 * 2) <= ws <= 252 * (2501 * 32 + 10 * 4900 * 2 + 10 * 4) + 4096
     assert lib.fp_workspace_bytes(0, 2501, 4900, 160, 160) == 0
     big = lib.fp_workspace_bytes(4, 100000, 200000, 160, 160)        # > 65535 triangles: 32-bit ids in the lists
     assert big >= 4 * (100000 * 32 + 10 * 200000 * 4)
