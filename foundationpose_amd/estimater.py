@@ -25,8 +25,13 @@ from .predict_score import ScorePredictor
 class FoundationPose:
     def __init__(self, model_pts, model_normals, symmetry_tfs=None, mesh=None, scorer: ScorePredictor = None,
                  refiner: PoseRefinePredictor = None, glctx=None, debug=0, debug_dir="/tmp/foundationpose_amd_debug",
-                 device="cuda"):
+                 device="cuda", track_graph=False):
+        """track_graph=True replays track_one as one captured hipGraph per frame (same arithmetic; off by default so
+        that the call sequence of the reference is followed literally)"""
         self.gt_pose = None
+        self.track_graph = bool(track_graph)
+        self._tracker = None
+        self._tracker_key = None
         self.ignore_normal_flip = True
         self.debug = debug
         self.debug_dir = debug_dir
@@ -42,6 +47,7 @@ class FoundationPose:
 
     # ------------------------------------------------------------------ estimater.py:44-78
     def reset_object(self, model_pts, model_normals, symmetry_tfs=None, mesh=None):
+        self._tracker = None   # a captured tracking graph holds the previous object's mesh
         max_xyz = np.asarray(mesh.vertices).max(axis=0)
         min_xyz = np.asarray(mesh.vertices).min(axis=0)
         self.model_center = (min_xyz + max_xyz) / 2
@@ -175,6 +181,19 @@ class FoundationPose:
         if self.pose_last is None:
             logging.info("Please init pose by register first")
             raise RuntimeError
+        if self.track_graph:
+            # same arithmetic, one hipGraph launch per frame (foundationpose_amd/graphs.py); re-captured when the
+            # frame size, intrinsics or iteration count change
+            key = (tuple(np.asarray(depth).shape[:2]), np.asarray(K, dtype=np.float64).tobytes(), int(iteration))
+            if self._tracker is None or self._tracker_key != key:
+                from .graphs import GraphedTracker
+                H, W = key[0]
+                self._tracker = GraphedTracker(self.refiner, self.mesh_tensors, self.diameter, K, H, W, n_hyp=1,
+                                               iteration=iteration, device=self.device).capture()
+                self._tracker_key = key
+            pose = self._tracker.step(rgb, depth, self.pose_last.reshape(1, 4, 4)).clone()
+            self.pose_last = pose
+            return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
         depth_t = torch.as_tensor(depth, device=self.device, dtype=torch.float).contiguous()
         depth_t = ops.erode_depth(depth_t, radius=2)
         depth_t = ops.bilateral_filter_depth(depth_t, radius=2)

@@ -1,0 +1,78 @@
+"""hipGraph capture of the per-frame tracking path (BASELINE configs[4]).
+
+`FoundationPose.track_one` (estimater.py:250-268) is, per frame: depth erosion -> bilateral filter -> back-projection
+-> `iteration` x (crop windows -> rasterise -> observed crop -> RefineNet -> pose update).  Shapes are static (frame
+size, number of hypotheses, iteration count), only values change, and every entry point of libfp_amd.so enqueues on
+the caller's stream without allocating or synchronising, so the whole frame is captured ONCE into a hipGraph (through
+torch.cuda.CUDAGraph, which also owns the private memory pool of the intermediate tensors) and replayed per frame:
+about 100 kernel launches per refine iteration collapse into one graph launch, and the pose stays on the device
+between frames (the reference does a .cpu()/.cuda() round trip and an empty_cache() per frame,
+estimater.py:263, predict_pose_refine.py:237).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .Utils import get_mesh_handle
+
+
+class GraphedTracker:
+    """Static-shape tracker: `step(rgb, depth[, poses])` -> refined poses (N,4,4) on the device (a view of a static
+    buffer, valid until the next call).  With `poses=None` the previous output is the next input (tracking)."""
+
+    def __init__(self, refiner, mesh_tensors, mesh_diameter, K, H, W, n_hyp=1, iteration=2, device=None):
+        self.refiner = refiner
+        self.handle = get_mesh_handle(mesh_tensors)
+        self.dev = torch.device(device) if device is not None else self.handle.device
+        self.K = np.asarray(K, dtype=np.float64).copy()
+        self.H, self.W, self.N, self.R = int(H), int(W), int(n_hyp), int(iteration)
+        self.diameter = float(mesh_diameter)
+        self.rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=self.dev)
+        self.depth = torch.zeros((H, W), dtype=torch.float32, device=self.dev)
+        self.poses_in = torch.eye(4, device=self.dev).repeat(self.N, 1, 1).contiguous()
+        self.poses_out = None
+        self.graph = None
+
+    def _body(self):
+        d = ops.bilateral_filter_depth(ops.erode_depth(self.depth, radius=2), radius=2)
+        xyz = ops.depth_to_xyz(d, self.K, zfar=float("inf"), f64_internal=False)     # depth2xyzmap_batch variant
+        poses, _, _ = self.refiner.refine_device(self.rgb, xyz, self.poses_in, self.K, self.H, self.W, self.handle,
+                                                 self.diameter, self.R)
+        return poses
+
+    @torch.inference_mode()
+    def capture(self):
+        """two eager warm-up runs on a side stream (lazy one-time initialisation inside the library and in PyTorch),
+        then the capture"""
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.poses_out = self._body()
+        return self
+
+    @torch.inference_mode()
+    def step(self, rgb, depth, poses=None):
+        if self.graph is None:
+            self.capture()
+        self.rgb.copy_(torch.as_tensor(rgb, device=self.dev), non_blocking=True)
+        self.depth.copy_(torch.as_tensor(depth, device=self.dev), non_blocking=True)
+        if poses is not None:
+            self.poses_in.copy_(torch.as_tensor(poses, device=self.dev, dtype=torch.float32).reshape(self.N, 4, 4))
+        elif self.poses_out is not None:
+            self.poses_in.copy_(self.poses_out)
+        self.graph.replay()
+        return self.poses_out
+
+    @torch.inference_mode()
+    def step_eager(self, rgb, depth, poses):
+        """the same frame without the graph (for A/B timing and the equality test)"""
+        self.rgb.copy_(torch.as_tensor(rgb, device=self.dev))
+        self.depth.copy_(torch.as_tensor(depth, device=self.dev))
+        self.poses_in.copy_(torch.as_tensor(poses, device=self.dev, dtype=torch.float32).reshape(self.N, 4, 4))
+        return self._body()

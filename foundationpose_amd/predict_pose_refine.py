@@ -127,35 +127,51 @@ class PoseRefinePredictor:
             self._plan_dev = dev
         return self._plan
 
+    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, AB=None):
+        """The refine loop on device tensors only (predict_pose_refine.py:182-235): per iteration fp_crop_windows ->
+        fp_render_crops (A) + fp_warp_crops (B) -> RefineNet plan -> fp_pose_update.  No host round trip, no host-side
+        tensor creation: the whole call is capturable in a hipGraph (foundationpose_amd/graphs.py).
+        -> (poses (N,4,4), last trans (N,3), last rot (N,3|6))"""
+        plan = self.plan()
+        N = poses.shape[0]
+        oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
+        tn = self.cfg["trans_normalizer"]
+        tn = [float(tn)] * 3 if isinstance(tn, (int, float)) else [float(v) for v in tn]
+        normalize = bool(self.cfg["normalize_xyz"])
+        if AB is None:
+            AB = torch.empty((2 * N, 6, oh, ow), dtype=plan.dtype, device=poses.device)
+        trans = rot = None
+        for _ in range(iteration):
+            tf_to_crops, bbox2d = ops.crop_windows(poses, K, mesh_diameter, self.cfg["crop_ratio"], (ow, oh))
+            if N == 2:
+                # reference broadcasting quirk (SURVEY App. D.5): with exactly two poses transform_pts pairs pose i with
+                # corner i, so both hypotheses are rendered with [umin_0, vmin_0, umax_1, vmax_1]
+                bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
+            ops.render_crops(mesh_handle, poses, bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
+                             xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[:N])
+            ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops, K, poses, mesh_diameter, ops.MODE_REFINE,
+                           normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[N:])
+            out = plan(AB)
+            trans, rot = out["trans"].contiguous(), out["rot"].contiguous()
+            poses = ops.pose_update(trans, rot, poses, rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
+                                    trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
+                                    mesh_diameter=float(mesh_diameter))
+        return poses, trans, rot
+
     @torch.inference_mode()
     def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None,
                 mesh_tensors=None, glctx=None, mesh_diameter=None, iteration=5):
         """@rgb (H,W,3) uint8/float np or tensor; @ob_in_cams (N,4,4) np or tensor.  -> ((N,4,4) f32 device tensor, vis)"""
-        plan = self.plan()
+        self.plan()
         dev = self._plan_dev
         if mesh_tensors is None:
             mesh_tensors = make_mesh_tensors(mesh, device=dev)
         B_in_cams = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous()
-        N = B_in_cams.shape[0]
         rgb_t = torch.as_tensor(rgb, device=dev).to(torch.float).contiguous()
-        depth_t = torch.as_tensor(depth, device=dev, dtype=torch.float).contiguous()
         xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
-        oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
-        tn = self.cfg["trans_normalizer"]
-        tn = [float(tn)] * 3 if isinstance(tn, (int, float)) else [float(v) for v in tn]
-        AB = torch.empty((2 * N, 6, oh, ow), dtype=plan.dtype, device=dev)
-        trans = rot = None
-        for _ in range(iteration):
-            batch = make_crop_data_batch(self.cfg["input_resize"], B_in_cams, mesh, rgb_t, depth_t, K,
-                                         crop_ratio=self.cfg["crop_ratio"], xyz_map=xyz_t, cfg=self.cfg, glctx=glctx,
-                                         mesh_tensors=mesh_tensors, dataset=self.dataset, mesh_diameter=mesh_diameter,
-                                         AB=AB)
-            out = plan(batch.AB)
-            trans, rot = out["trans"].contiguous(), out["rot"].contiguous()
-            B_in_cams = ops.pose_update(trans, rot, batch.poseA, rot_rep=self.cfg["rot_rep"],
-                                        normalize_xyz=bool(self.cfg["normalize_xyz"]), trans_normalizer=tn,
-                                        rot_normalizer=float(self.cfg["rot_normalizer"]),
-                                        mesh_diameter=float(mesh_diameter))
+        H, W = int(rgb_t.shape[0]), int(rgb_t.shape[1])
+        B_in_cams, trans, rot = self.refine_device(rgb_t, xyz_t, B_in_cams, K, H, W, get_mesh_handle(mesh_tensors),
+                                                   mesh_diameter, iteration)
         self.last_trans_update = trans
         self.last_rot_update = rot
         if get_vis:

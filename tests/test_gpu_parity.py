@@ -514,3 +514,46 @@ def test_fp16_plans_match_fp32_plans(dev):
     f32 = engine.ScorePlan(net, dev, precision="fp32").features(AB)
     f16 = engine.ScorePlan(net, dev, precision="fp16").features(AB.half())
     np.testing.assert_allclose(f16.float().cpu().numpy(), f32.cpu().numpy(), atol=3e-2 * max(1.0, float(f32.abs().max())))
+
+
+# ------------------------------------------------------------------ hipGraph-captured tracking
+def test_graphed_tracker_replays_the_eager_result(scene, dev, gmesh, frame):
+    """one captured graph per (frame size, N, iterations); replay == eager bit for bit, for changing inputs"""
+    from foundationpose_amd.graphs import GraphedTracker
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev)
+    P = scene["poses"][::32][:8]
+    trk = GraphedTracker(refiner, gmesh, scene["diameter"], scene["K"], 480, 640, n_hyp=len(P), iteration=2, device=dev).capture()
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        rgb = np.clip(scene["rgb"].astype(np.float32) + rng.normal(0, 3 * k, scene["rgb"].shape), 0, 255).astype(np.float32)
+        depth = (scene["depth"] + 0.002 * k).astype(np.float32)
+        Pk = P.copy()
+        Pk[:, :3, 3] += 0.003 * k
+        eager = trk.step_eager(rgb, depth, Pk).clone()
+        replay = trk.step(rgb, depth, Pk).clone()
+        assert torch.equal(eager, replay), k
+    # tracking mode: the previous output feeds the next frame without leaving the device
+    a = trk.step(scene["rgb"].astype(np.float32), scene["depth"], P).clone()
+    b = trk.step(scene["rgb"].astype(np.float32), scene["depth"]).clone()
+    c = trk.step_eager(scene["rgb"].astype(np.float32), scene["depth"], a.cpu().numpy())
+    assert torch.equal(b, c)
+
+
+def test_estimator_track_graph_matches_eager(scene, dev):
+    from foundationpose_amd.estimater import FoundationPose
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    mesh = scene["mesh"]
+    refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev)
+    scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), device=dev)
+    out = {}
+    for graph in (False, True):
+        est = FoundationPose(model_pts=mesh.vertices, model_normals=mesh.vertex_normals, mesh=mesh, scorer=scorer,
+                             refiner=refiner, device=dev, track_graph=graph)
+        est.pose_last = torch.as_tensor(scene["gt"], device=dev, dtype=torch.float)
+        seq = [est.track_one(scene["rgb"], scene["depth"], scene["K"], iteration=2) for _ in range(3)]
+        out[graph] = np.stack(seq)
+    assert np.array_equal(out[False], out[True])
