@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime with PyTorch)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfp_amd.so")
+LIB_PATH = os.environ.get("FP_AMD_LIB") or os.path.join(_HERE, "csrc", "libfp_amd.so")   # FP_AMD_LIB: A/B builds
 _lib = None
 
 vp, ci, cf, cd, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t

@@ -26,46 +26,9 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include <string.h>
-#include "fp_common.h"
+#include "igemm_common.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float float16_ __attribute__((ext_vector_type(16)));
-
-#define IG_BK 64
-
-struct IgemmGeom {      // row m -> element offset of pixel (b, y*stride + pad_off, x*stride + pad_off) in a padded NHWC buffer
-  int HoWo, Wo;         // output pixels per image / per row (1,1 for a plain GEMM)
-  int Hp, Wp;           // padded height / width of the buffer
-  int stride;           // spatial stride applied to (oy, ox)
-  int off;              // border offset added to the pixel position (0 for the conv input: tap (0,0) = top-left pad)
-  int cstride;          // channels per pixel in the buffer
-  int coff;             // first channel
-  int bsplit;           // image b -> (b % bsplit), channel group (b / bsplit) * cgroup  (0 = off)
-  int cgroup;
-};
-
-struct IgemmParams {
-  const _Float16* A;
-  const _Float16* Wt;   // [N][taps*Cin]
-  const float* bias;    // [N] or null
-  const _Float16* R;    // residual or null
-  _Float16* Y;
-  int M, N, Cin, taps;
-  int relu;
-  IgemmGeom in, out, res;
-};
-
-__device__ __forceinline__ long long ig_row_off(const IgemmGeom& g, int m) {
-  const int b = m / g.HoWo;
-  const int r = m - b * g.HoWo;
-  const int oy = r / g.Wo;
-  const int ox = r - oy * g.Wo;
-  int bb = b, cg = 0;
-  if (g.bsplit > 0) { cg = b / g.bsplit; bb = b - cg * g.bsplit; }
-  return (((long long)bb * g.Hp + (oy * g.stride + g.off)) * g.Wp + (ox * g.stride + g.off)) * g.cstride + g.coff +
-         (long long)cg * g.cgroup;
-}
+int fp_conv3x3s1_launch(const IgemmParams& p, int B, hipStream_t stream);   // conv3x3.hip
 
 // Workgroup tile BM (pixels) x BN (channels) x 64 (k); every wave owns (32*TM) x 64 outputs as TM x 2
 // v_mfma_f32_32x32x16_f16 tiles; NST LDS stages (prefetch distance NST-1 k-steps, counted vmcnt + raw s_barrier).
@@ -299,6 +262,17 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = bias; p.R = (const _Float16*)residual; p.Y = (_Float16*)y;
   p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = relu;
   p.in = ig_geom(x_geom); p.out = ig_geom(y_geom); p.res = residual ? ig_geom(r_geom) : ig_geom(y_geom);
+  // FP_CONV3X3=1: stride-1 3x3 convolutions whose input and output share one padded pixel grid go to the
+  // shifted-window kernel (conv3x3.hip: the 9 taps read one LDS-resident input patch instead of 9 operand streams).
+  // Off by default: 1.7-2.3x less operand traffic bought nothing on MI355X (770 vs 763 TFLOP/s nominal at 256
+  // channels, and it computes the border pixels too), which is what ruled the operand stream out as the bound.
+  static int use_sw = -1;
+  if (use_sw < 0) { const char* e = getenv("FP_CONV3X3"); use_sw = e ? atoi(e) : 0; }   // measured: not faster
+  if (use_sw && taps == 9 && p.in.stride == 1 && p.in.off == 0 && p.in.bsplit == 0 && p.in.coff % 8 == 0 &&
+      p.in.Hp * p.in.Wp == (p.in.HoWo / p.in.Wo + 2) * (p.in.Wo + 2) && p.in.Wp == p.in.Wo + 2 && p.in.Wp <= 63 &&
+      M % p.in.HoWo == 0 && M >= 1024 && p.out.HoWo == p.in.HoWo && p.out.Wo == p.in.Wo && p.out.stride == 1 &&
+      (!residual || (p.res.HoWo == p.in.HoWo && p.res.Wo == p.in.Wo && p.res.stride == 1)))
+    return fp_conv3x3s1_launch(p, M / p.in.HoWo, (hipStream_t)stream);
   // tile selection; FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | 512x128 forces one (profiling aid)
   static int forced = -1;
   if (forced < 0) {

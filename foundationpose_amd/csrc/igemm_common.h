@@ -1,0 +1,44 @@
+// Shared by igemm.hip and conv3x3.hip: operand addressing and the kernel parameter block of fp_igemm_f16_fwd.
+#pragma once
+#include <hip/hip_fp16.h>
+#include "fp_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16_ __attribute__((ext_vector_type(16)));
+
+#define IG_BK 64
+
+struct IgemmGeom {      // row m -> element offset of pixel (b, y*stride + pad_off, x*stride + pad_off) in a padded NHWC buffer
+  int HoWo, Wo;         // output pixels per image / per row (1,1 for a plain GEMM)
+  int Hp, Wp;           // padded height / width of the buffer
+  int stride;           // spatial stride applied to (oy, ox)
+  int off;              // border offset added to the pixel position (0 for the conv input: tap (0,0) = top-left pad)
+  int cstride;          // channels per pixel in the buffer
+  int coff;             // first channel
+  int bsplit;           // image b -> (b % bsplit), channel group (b / bsplit) * cgroup  (0 = off)
+  int cgroup;
+};
+
+struct IgemmParams {
+  const _Float16* A;
+  const _Float16* Wt;   // [N][taps*Cin]
+  const float* bias;    // [N] or null
+  const _Float16* R;    // residual or null
+  _Float16* Y;
+  int M, N, Cin, taps;
+  int relu;
+  IgemmGeom in, out, res;
+};
+
+__device__ __forceinline__ long long ig_row_off(const IgemmGeom& g, int m) {
+  const int b = m / g.HoWo;
+  const int r = m - b * g.HoWo;
+  const int oy = r / g.Wo;
+  const int ox = r - oy * g.Wo;
+  int bb = b, cg = 0;
+  if (g.bsplit > 0) { cg = b / g.bsplit; bb = b - cg * g.bsplit; }
+  return (((long long)bb * g.Hp + (oy * g.stride + g.off)) * g.Wp + (ox * g.stride + g.off)) * g.cstride + g.coff +
+         (long long)cg * g.cgroup;
+}
+
