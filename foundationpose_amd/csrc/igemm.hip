@@ -48,7 +48,8 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   constexpr int LPS = AI + WI;
   constexpr int CPR = BN / 8;                      // 16-byte chunks per row of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
   const int wm = wid / NWN, wn = wid - wm * NWN;   // wave position: pixels (m) x channels (n)
 
   // ---- XCD-aware tile order (bijective for any grid size)
@@ -61,42 +62,50 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
 
-  // ---- per-thread staging sources: wave w loads rows [8*AI*w, +8*AI) of the A tile and [8*WI*w, +8*WI) of the W tile
-  const _Float16* asrc[AI];
-  const _Float16* wsrc[WI];
+  // ---- per-thread staging sources: wave w loads rows [8*AI*w, +8*AI) of the A tile and [8*WI*w, +8*WI) of the W tile.
+  // Kept as 32-bit byte offsets from the (uniform) tensor bases, so that the per-k-step part of every address is a
+  // scalar and the LDS-DMA takes the saddr + voffset form: no vector ALU work per load (the first version spent more
+  // issue slots on 64-bit address adds and on an integer division per k-step than on MFMAs).
+  unsigned aoff32[AI], woff32[WI];
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int row = wid * (AI * 8) + j * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);   // logical chunk that lands in physical chunk (lane & 7)
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    asrc[j] = p.A + ig_row_off(p.in, m) + c * 8;
+    aoff32[j] = (unsigned)((ig_row_off(p.in, m) + c * 8) * 2);
   }
 #pragma unroll
   for (int j = 0; j < WI; ++j) {
     const int row = wid * (WI * 8) + j * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    wsrc[j] = p.Wt + (size_t)(n0 + row) * Ktot + c * 8;
+    woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
   }
-  const int cpt = p.Cin / IG_BK;            // k-steps per tap
-  const int nk = p.taps * cpt;
+  const int nk = p.taps * (p.Cin / IG_BK);
+  // running state of the NEXT k-step to stage: (ky, kx, ci0) advance without divisions; all scalar
+  int st_ci0 = 0, st_kx = 0, st_ky = 0, st_k = 0;
+  const int inWp = p.in.Wp, inCs = p.in.cstride, Cin = p.Cin;
+  // buffer descriptors (wave-uniform): LDS-DMA as `buffer_load_dwordx4 voff, rsrc, soff offen lds` -- per-lane byte
+  // offset in a VGPR computed once, per-k-step offset in an SGPR, LDS destination in M0: no vector ALU work per load
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Wt), 0, 0x7FFFFFFF, 0x00020000);
 
-  auto stage = [&](int ks, int buf) {
-    const int tap = ks / cpt;
-    const int ci0 = (ks - tap * cpt) * IG_BK;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const long long aoff = ((long long)ky * p.in.Wp + kx) * p.in.cstride + ci0;   // 0 + ci0 for a plain GEMM (taps = 1)
-    const int woff = ks * IG_BK;
+  auto stage = [&](int buf) {
+    const int asoff = (((st_ky * inWp + st_kx) * inCs) + st_ci0) * 2;   // bytes; just ci0 for a plain GEMM (taps = 1)
+    const int wsoff = st_k * (IG_BK * 2);
     unsigned char* sa = smem + buf * STAGE_BYTES + wid * (AI * 1024);
     unsigned char* sw = smem + buf * STAGE_BYTES + A_BYTES + wid * (WI * 1024);
 #pragma unroll
     for (int j = 0; j < AI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + aoff),
-                                       (__attribute__((address_space(3))) void*)(sa + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sa + j * 1024), 16,
+                                               (int)aoff32[j], asoff, 0, 0);
 #pragma unroll
     for (int j = 0; j < WI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + woff),
-                                       (__attribute__((address_space(3))) void*)(sw + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sw + j * 1024), 16,
+                                               (int)woff32[j], wsoff, 0, 0);
+    ++st_k;
+    st_ci0 += IG_BK;
+    if (st_ci0 == Cin) { st_ci0 = 0; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
   };
 
   float16_ acc[2][TM];   // [channel tile i][pixel tile j]
@@ -107,23 +116,26 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // fragment read addressing: lane reads row (lane & 31), logical chunk 2*kk + (lane >> 5)
+  // fragment read addressing: lane reads row (lane & 31), logical chunk 2*kk + (lane >> 5); the swizzled byte offsets
+  // of the 4 k-substeps are computed once, a read costs one add of the (scalar) stage base
   const int frow = lane & 31, fhalf = lane >> 5;
-  int a_rowb[TM], a_sw[TM], w_rowb[2], w_sw[2];
+  int a_off[TM][4], w_off[2][4];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int ra = wm * (32 * TM) + t * 32 + frow;
-    a_rowb[t] = ra * 128; a_sw[t] = (ra >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a_off[t][kk] = ra * 128 + (((2 * kk + fhalf) ^ ((ra >> 1) & 7)) << 4);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int rw = wn * 64 + t * 32 + frow;
-    w_rowb[t] = rw * 128; w_sw[t] = (rw >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) w_off[t][kk] = A_BYTES + rw * 128 + (((2 * kk + fhalf) ^ ((rw >> 1) & 7)) << 4);
   }
 
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) stage(s, s);
+    if (s < nk) stage(s);
   int buf = 0, nbuf = NST - 1;
   for (int ks = 0; ks < nk; ++ks) {
     // stage ks must have landed; the NST-2 stages issued after it may stay in flight (loads retire in order)
@@ -135,17 +147,15 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();     // everyone's part of stage ks is visible; everyone is done reading stage ks-1
-    if (ks + NST - 1 < nk) stage(ks + NST - 1, nbuf);
-    const unsigned char* sa = smem + buf * STAGE_BYTES;
-    const unsigned char* sw = sa + A_BYTES;
+    if (ks + NST - 1 < nk) stage(nbuf);
+    const unsigned char* sb = smem + buf * STAGE_BYTES;
     // fragment double buffer: the ds_read_b128 of k-substep kk+1 are issued before the MFMAs of kk
     half8 fa[2][TM], fw[2][2];
     auto load_frags = [&](int kk, int slot) {
-      const int c = 2 * kk + fhalf;
 #pragma unroll
-      for (int t = 0; t < TM; ++t) fa[slot][t] = *reinterpret_cast<const half8*>(sa + a_rowb[t] + ((c ^ a_sw[t]) << 4));
+      for (int t = 0; t < TM; ++t) fa[slot][t] = *reinterpret_cast<const half8*>(sb + a_off[t][kk]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fw[slot][t] = *reinterpret_cast<const half8*>(sw + w_rowb[t] + ((c ^ w_sw[t]) << 4));
+      for (int t = 0; t < 2; ++t) fw[slot][t] = *reinterpret_cast<const half8*>(sb + w_off[t][kk]);
     };
     load_frags(0, 0);
 #pragma unroll
