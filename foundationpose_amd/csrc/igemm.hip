@@ -252,6 +252,9 @@ static IgemmGeom ig_geom(const fp_igemm_geom* g) {
   IgemmGeom o;
   o.HoWo = g->pixels_per_image; o.Wo = g->width; o.Hp = g->padded_h; o.Wp = g->padded_w; o.stride = g->stride;
   o.off = g->offset; o.cstride = g->cstride; o.coff = g->coff; o.bsplit = g->bsplit; o.cgroup = g->cgroup;
+  ig_fastdiv_init(o.HoWo, &o.mulP, &o.shrP);
+  ig_fastdiv_init(o.Wo, &o.mulW, &o.shrW);
+  ig_fastdiv_init(o.bsplit, &o.mulB, &o.shrB);
   return o;
 }
 
@@ -297,8 +300,8 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   }
   int sel = forced;
   // measured at the bench shapes (scripts/bench_igemm.py): 256x256 wins where both M and N are large
-  // (256->256 convs 868 vs 821 TFLOP/s, QKV projection 637 vs 527), 128x128 (two workgroups per CU) elsewhere
-  if (sel == 0) sel = ((N % 256) == 0 && M >= 150000) ? 3 : 1;
+  // (256->256 convs 947 vs 899 TFLOP/s, QKV projection 688 vs 561), 128x128 (two workgroups per CU) elsewhere
+  if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 3 : 1;
   if (sel == 3 && (N % 256) != 0) sel = 4;
   switch (sel) {
     case 1: return ig_launch<128, 128, 2, 2>(p, (hipStream_t)stream);

@@ -18,7 +18,24 @@ struct IgemmGeom {      // row m -> element offset of pixel (b, y*stride + pad_o
   int coff;             // first channel
   int bsplit;           // image b -> (b % bsplit), channel group (b / bsplit) * cgroup  (0 = off)
   int cgroup;
+  unsigned mulP, shrP;  // n / HoWo, n / Wo, n / bsplit as umulhi(n, mul) >> shr (host-computed, exact for n < 2^31)
+  unsigned mulW, shrW;
+  unsigned mulB, shrB;
 };
+
+// division by a runtime constant without the ~40-instruction emulated divide (the row -> address maps run 20 times per
+// thread and tile): mul == 0 encodes divisor 1
+static inline void ig_fastdiv_init(int d, unsigned* mul, unsigned* shr) {
+  if (d <= 1) { *mul = 0; *shr = 0; return; }
+  int lg = 0;
+  while ((1u << lg) < (unsigned)d) ++lg;              // ceil(log2 d)
+  const int p = 31 + lg;
+  *mul = (unsigned)(((1ull << p) + (unsigned)d - 1) / (unsigned)d);
+  *shr = (unsigned)(p - 32);
+}
+__device__ __forceinline__ int ig_fastdiv(int n, unsigned mul, unsigned shr) {
+  return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+}
 
 struct IgemmParams {
   const _Float16* A;
@@ -32,12 +49,12 @@ struct IgemmParams {
 };
 
 __device__ __forceinline__ long long ig_row_off(const IgemmGeom& g, int m) {
-  const int b = m / g.HoWo;
+  const int b = ig_fastdiv(m, g.mulP, g.shrP);
   const int r = m - b * g.HoWo;
-  const int oy = r / g.Wo;
+  const int oy = ig_fastdiv(r, g.mulW, g.shrW);
   const int ox = r - oy * g.Wo;
   int bb = b, cg = 0;
-  if (g.bsplit > 0) { cg = b / g.bsplit; bb = b - cg * g.bsplit; }
+  if (g.bsplit > 0) { cg = ig_fastdiv(b, g.mulB, g.shrB); bb = b - cg * g.bsplit; }
   return (((long long)bb * g.Hp + (oy * g.stride + g.off)) * g.Wp + (ox * g.stride + g.off)) * g.cstride + g.coff +
          (long long)cg * g.cgroup;
 }
