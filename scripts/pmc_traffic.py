@@ -7,32 +7,38 @@ coalesced read stream (x2); WRITE_SIZE is taken as is.
 """
 import collections, csv, json, os, sys
 
-ENTRY = {"k_render": "fp_render_crops", "k_warp": "fp_warp_crops", "k_conv7x7s2": "fp_conv7x7s2_bn_relu_fwd",
+ENTRY = {"k_vertex": "fp_render_crops", "k_bin": "fp_render_crops", "k_raster": "fp_render_crops", "k_warp": "fp_warp_crops", "k_conv7x7s2": "fp_conv7x7s2_bn_relu_fwd",
          "k_igemm_f16": "fp_igemm_f16_fwd", "k_linear_f16": "fp_linear_f16_fwd", "k_layernorm512": "fp_layernorm_f16_fwd",
          "k_colmean512": "fp_colmean_f16_fwd"}
 
 
 def load(path, counter):
-    agg = collections.defaultdict(list)
+    per_kernel = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        for k, e in ENTRY.items():
+        for k in ENTRY:
             if k in r["Kernel_Name"]:
-                agg[e].append(float(r["Counter_Value"]))
-    return agg
+                per_kernel[k].append(float(r["Counter_Value"]))
+    # an entry point that is several kernels (fp_render_crops = k_vertex + k_bin + k_raster): sum of the per-kernel
+    # means over the warm launches
+    agg = collections.defaultdict(float)
+    n = {}
+    for k, vals in per_kernel.items():
+        warm = vals[1:] or vals
+        agg[ENTRY[k]] += sum(warm) / len(warm)
+        n[ENTRY[k]] = len(warm)
+    return agg, n
 
 
 def main():
-    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    (fetch, nf), (write, _) = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {}
     for e in sorted(set(fetch) | set(write)):
-        f = fetch.get(e, [0.0])[1:] or fetch.get(e, [0.0])   # drop the first (cold) launch when there are several
-        w = write.get(e, [0.0])[1:] or write.get(e, [0.0])
-        fb = 2.0 * 1024.0 * sum(f) / len(f)
-        wb = 1024.0 * sum(w) / len(w)
+        fb = 2.0 * 1024.0 * fetch.get(e, 0.0)
+        wb = 1024.0 * write.get(e, 0.0)
         out[e] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
-                  "launches": len(f), "note": "FETCH_SIZE x2 (gfx950), KB -> bytes; mean over the warm launches of scripts/run_kernels.py"}
+                  "launches": nf.get(e, 0), "note": "FETCH_SIZE x2 (gfx950), KB -> bytes; mean over the warm launches of scripts/run_kernels.py"}
     path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
