@@ -557,3 +557,77 @@ def test_estimator_track_graph_matches_eager(scene, dev):
         seq = [est.track_one(scene["rgb"], scene["depth"], scene["K"], iteration=2) for _ in range(3)]
         out[graph] = np.stack(seq)
     assert np.array_equal(out[False], out[True])
+
+
+# ------------------------------------------------------------------ edge cases of the predictors
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_refiner_small_batches_incl_two_pose_quirk(scene, dev, gmesh, frame, n):
+    """N=1 (tracking), N=2 (the reference's transform_pts broadcasting quirk, SURVEY App. D.5: both hypotheses are
+    rendered with [umin_0, vmin_0, umax_1, vmax_1]) and an odd N"""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    from oracle import pipeline as op
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = random_state_dict("refine", cfg, seed=0)
+    P0 = scene["poses"][[3, 77, 140, 201, 250][:n]].copy()
+    if n == 2:
+        P0[1, :3, 3] += [0.02, -0.01, 0.03]   # different windows, so that the quirk changes the render
+    ref = op.refine_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, frame["xyz"], scene["mesh_np"],
+                            scene["diameter"], iteration=1)
+    pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp32")
+    out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"],
+                          mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=1)
+    out = out.cpu().numpy()
+    assert out.shape == (n, 4, 4)
+    assert _geodesic(out[:, :3, :3], ref[:, :3, :3]).max() <= 1e-4
+    assert np.linalg.norm(out[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= 1e-4
+    p16 = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16")
+    o16, _ = p16.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"],
+                         mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=2)
+    assert o16.shape == (n, 4, 4) and torch.isfinite(o16).all()
+
+
+@pytest.mark.parametrize("use_bn,rot_rep,normalize", [(False, "6d", False), (True, "6d", True), (False, "axis_angle", True)])
+def test_refiner_config_variants_match_oracle(scene, dev, frame, use_bn, rot_rep, normalize):
+    """use_BN / rot_rep / normalize_xyz are unknown until real checkpoints are available: all combinations
+    of the code paths must match the oracle; vertex-colour mesh instead of a texture"""
+    from foundationpose_amd.mesh import make_can_mesh
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.Utils import make_mesh_tensors
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    from oracle import pipeline as op
+    cfg = dict(DEFAULT_REFINE_CFG, use_BN=use_bn, rot_rep=rot_rep, normalize_xyz=normalize)
+    sd = random_state_dict("refine", cfg, seed=5)
+    mesh = make_can_mesh(textured=False)
+    gm = make_mesh_tensors(mesh, device=dev)
+    P0 = scene["poses"][::40]
+    ref = op.refine_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, frame["xyz"], op.mesh_tensors_np(mesh),
+                            scene["diameter"], iteration=1)
+    for prec, tolR, tolt in (("fp32", 1e-4, 1e-4), ("fp16", 3e-2, 3e-3)):
+        pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision=prec)
+        out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=mesh, mesh_tensors=gm,
+                              mesh_diameter=scene["diameter"], iteration=1)
+        out = out.cpu().numpy()
+        assert _geodesic(out[:, :3, :3], ref[:, :3, :3]).max() <= tolR, prec
+        assert np.linalg.norm(out[:, :3, 3] - ref[:, :3, 3], axis=1).max() <= tolt, prec
+
+
+def test_scorer_single_hypothesis_and_fp16_ranking(scene, dev, gmesh, frame):
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_SCORE_CFG, random_state_dict
+    from oracle import pipeline as op
+    cfg = dict(DEFAULT_SCORE_CFG)
+    sd = random_state_dict("score", cfg, seed=0)
+    one, _ = ScorePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp32").predict(
+        scene["rgb"], frame["depth_t"], scene["K"], scene["poses"][:1], mesh=scene["mesh"], mesh_tensors=gmesh,
+        mesh_diameter=scene["diameter"])
+    ref1 = op.score_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], scene["poses"][:1], scene["mesh_np"], scene["diameter"])
+    assert one.shape == (1,) and abs(float(one[0]) - float(ref1[0])) < 1e-3 * max(1.0, abs(float(ref1[0]) - 100))
+    P0 = scene["poses"][::8]
+    ref = op.score_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, scene["mesh_np"], scene["diameter"])
+    s16, _ = ScorePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16").predict(
+        scene["rgb"], frame["depth_t"], scene["K"], P0, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    s16 = s16.cpu().numpy()
+    assert np.abs(s16 - ref).max() < 0.25 * max(1.0, ref.std())      # fp16 deployment vs fp32 oracle
+    top = np.argsort(-ref)[:3]
+    assert np.argmax(s16) in top                                       # the fp16 winner is among the oracle's top 3
