@@ -36,15 +36,23 @@ int fp_conv3x3s1_launch(const IgemmParams& p, int B, hipStream_t stream);   // c
 // regardless of prefetch depth -- they are bound by the issue cost of their own LDS-DMA (6-8 global_load_lds per
 // wave against 16 MFMAs per k-step), so the lever is FLOP per staged byte: 4x2 tiles per wave in a 256x256 or
 // 512x128 workgroup tile halve the DMA instructions per MFMA and cut the fragment reads per MFMA by 25 %.
-template <int BM, int BN, int TM, int NST>
+template <int BM, int BN, int TM, int NST, int BK>
 __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_f16(IgemmParams p) {
   constexpr int NWN = BN / 64;
   constexpr int NW = (BM / (32 * TM)) * NWN;
   constexpr int THREADS = NW * 64;
-  constexpr int A_BYTES = BM * IG_BK * 2;
-  constexpr int STAGE_BYTES = A_BYTES + BN * IG_BK * 2;
-  constexpr int AI = BM / 8 / NW;                  // A-tile LDS-DMA instructions per wave and stage
-  constexpr int WI = BN / 8 / NW;                  // W-tile ...
+  constexpr int ROWB = BK * 2;                     // bytes per LDS row (one pixel / one output channel, BK halves)
+  constexpr int CPK = BK / 8;                      // 16-byte chunks per row: 8 (BK=64) or 4 (BK=32)
+  constexpr int RPI = 1024 / ROWB;                 // rows per LDS-DMA instruction (64 lanes x 16 B)
+  constexpr int KK = BK / 16;                      // MFMA k-substeps per stage
+  constexpr int A_BYTES = BM * ROWB;
+  constexpr int STAGE_BYTES = A_BYTES + BN * ROWB;
+  constexpr int AI = BM / RPI / NW;                // A-tile LDS-DMA instructions per wave and stage
+  constexpr int WI = BN / RPI / NW;                // W-tile ...
+  static_assert(AI >= 1 && WI >= 1, "tile too small for this wave count");
+  // XOR swizzle of the chunk index: 16 rows of a ds_read_b128 lane group must land on 16 distinct 16-byte slots of
+  // the 256-byte bank row, which holds 2 rows at BK=64 and 4 rows at BK=32
+  auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   constexpr int LPS = AI + WI;
   constexpr int CPR = BN / 8;                      // 16-byte chunks per row of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -69,19 +77,19 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   unsigned aoff32[AI], woff32[WI];
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
-    const int row = wid * (AI * 8) + j * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);   // logical chunk that lands in physical chunk (lane & 7)
+    const int row = wid * (AI * RPI) + j * RPI + lane / CPK;
+    const int c = (lane % CPK) ^ swz(row);   // logical chunk that lands in physical chunk (lane % CPK)
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
     aoff32[j] = (unsigned)((ig_row_off(p.in, m) + c * 8) * 2);
   }
 #pragma unroll
   for (int j = 0; j < WI; ++j) {
-    const int row = wid * (WI * 8) + j * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = wid * (WI * RPI) + j * RPI + lane / CPK;
+    const int c = (lane % CPK) ^ swz(row);
     woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
   }
-  const int nk = p.taps * (p.Cin / IG_BK);
+  const int nk = p.taps * (p.Cin / BK);
   // running state of the NEXT k-step to stage: (ky, kx, ci0) advance without divisions; all scalar
   int st_ci0 = 0, st_kx = 0, st_ky = 0, st_k = 0;
   const int inWp = p.in.Wp, inCs = p.in.cstride, Cin = p.Cin;
@@ -92,7 +100,7 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
 
   auto stage = [&](int buf) {
     const int asoff = (((st_ky * inWp + st_kx) * inCs) + st_ci0) * 2;   // bytes; just ci0 for a plain GEMM (taps = 1)
-    const int wsoff = st_k * (IG_BK * 2);
+    const int wsoff = st_k * (BK * 2);
     unsigned char* sa = smem + buf * STAGE_BYTES + wid * (AI * 1024);
     unsigned char* sw = smem + buf * STAGE_BYTES + A_BYTES + wid * (WI * 1024);
 #pragma unroll
@@ -104,7 +112,7 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sw + j * 1024), 16,
                                                (int)woff32[j], wsoff, 0, 0);
     ++st_k;
-    st_ci0 += IG_BK;
+    st_ci0 += BK;
     if (st_ci0 == Cin) { st_ci0 = 0; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
   };
 
@@ -119,18 +127,18 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   // fragment read addressing: lane reads row (lane & 31), logical chunk 2*kk + (lane >> 5); the swizzled byte offsets
   // of the 4 k-substeps are computed once, a read costs one add of the (scalar) stage base
   const int frow = lane & 31, fhalf = lane >> 5;
-  int a_off[TM][4], w_off[2][4];
+  int a_off[TM][KK], w_off[2][KK];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int ra = wm * (32 * TM) + t * 32 + frow;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) a_off[t][kk] = ra * 128 + (((2 * kk + fhalf) ^ ((ra >> 1) & 7)) << 4);
+    for (int kk = 0; kk < KK; ++kk) a_off[t][kk] = ra * ROWB + (((2 * kk + fhalf) ^ swz(ra)) << 4);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int rw = wn * 64 + t * 32 + frow;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) w_off[t][kk] = A_BYTES + rw * 128 + (((2 * kk + fhalf) ^ ((rw >> 1) & 7)) << 4);
+    for (int kk = 0; kk < KK; ++kk) w_off[t][kk] = A_BYTES + rw * ROWB + (((2 * kk + fhalf) ^ swz(rw)) << 4);
   }
 
 #pragma unroll
@@ -140,9 +148,12 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   for (int ks = 0; ks < nk; ++ks) {
     // stage ks must have landed; the NST-2 stages issued after it may stay in flight (loads retire in order)
     if (NST > 2 && ks + NST - 2 < nk) {
-      static_assert(NST <= 2 || LPS * (NST - 2) == 6 || LPS * (NST - 2) == 8, "add the counted wait for this shape");
-      if (LPS * (NST - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      constexpr int INFLIGHT = LPS * (NST - 2);
+      static_assert(NST <= 2 || INFLIGHT == 4 || INFLIGHT == 6 || INFLIGHT == 8 || INFLIGHT == 12, "add the counted wait");
+      if (INFLIGHT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -159,8 +170,8 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
     };
     load_frags(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 3) load_frags(kk + 1, (kk + 1) & 1);
+    for (int kk = 0; kk < KK; ++kk) {
+      if (kk < KK - 1) load_frags(kk + 1, (kk + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (hipcc otherwise sinks it below them)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -219,9 +230,9 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   }
 }
 
-template <int BM, int BN, int TM, int NST>
+template <int BM, int BN, int TM, int NST, int BK>
 static int ig_launch(const IgemmParams& p, hipStream_t stream) {
-  constexpr int STAGES = NST * (BM + BN) * IG_BK * 2;
+  constexpr int STAGES = NST * (BM + BN) * BK * 2;
   constexpr int ETILE = BM * BN * 2;
   constexpr int LDS = STAGES > ETILE ? STAGES : ETILE;
   constexpr int THREADS = (BM / (32 * TM)) * (BN / 64) * 64;
@@ -230,11 +241,11 @@ static int ig_launch(const IgemmParams& p, hipStream_t stream) {
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_f16<BM, BN, TM, NST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_f16<BM, BN, TM, NST, BK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_igemm_f16<BM, BN, TM, NST>), dim3((unsigned)tiles), dim3(THREADS), LDS, stream, p);
+  hipLaunchKernelGGL((k_igemm_f16<BM, BN, TM, NST, BK>), dim3((unsigned)tiles), dim3(THREADS), LDS, stream, p);
   FP_CHECK_LAUNCH("fp_igemm_f16_fwd");
   return FP_OK;
 }
@@ -266,7 +277,7 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   FP_REQUIRE(x && w && y && x_geom && y_geom, "fp_igemm_f16_fwd: NULL tensor / geometry");
   FP_REQUIRE(taps == 1 || taps == 9, "fp_igemm_f16_fwd: taps must be 1 (GEMM) or 9 (3x3 conv), got %d", taps);
   FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
-  FP_REQUIRE(Cin > 0 && Cin % IG_BK == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of %d", Cin, IG_BK);
+  FP_REQUIRE(Cin > 0 && Cin % 64 == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of 64", Cin);
   FP_REQUIRE(!residual || r_geom, "fp_igemm_f16_fwd: residual without geometry");
   if (int e = ig_check_geom(x_geom, "input")) return e;
   if (int e = ig_check_geom(y_geom, "output")) return e;
@@ -296,6 +307,8 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
       else if (!strcmp(e, "256x128")) forced = 2;
       else if (!strcmp(e, "256x256")) forced = 3;
       else if (!strcmp(e, "512x128")) forced = 4;
+      else if (!strcmp(e, "128x128k32x3")) forced = 5;
+      else if (!strcmp(e, "128x128k32x4")) forced = 6;
     }
   }
   int sel = forced;
@@ -304,10 +317,12 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 3 : 1;
   if (sel == 3 && (N % 256) != 0) sel = 4;
   switch (sel) {
-    case 1: return ig_launch<128, 128, 2, 2>(p, (hipStream_t)stream);
-    case 2: return ig_launch<256, 128, 2, 3>(p, (hipStream_t)stream);
-    case 3: return ig_launch<256, 256, 4, 2>(p, (hipStream_t)stream);
-    default: return ig_launch<512, 128, 4, 2>(p, (hipStream_t)stream);
+    case 1: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
+    case 2: return ig_launch<256, 128, 2, 3, 64>(p, (hipStream_t)stream);
+    case 3: return ig_launch<256, 256, 4, 2, 64>(p, (hipStream_t)stream);
+    case 5: return ig_launch<128, 128, 2, 3, 32>(p, (hipStream_t)stream);   // 48 KiB: three workgroups per CU
+    case 6: return ig_launch<128, 128, 2, 4, 32>(p, (hipStream_t)stream);   // 64 KiB: prefetch distance 3
+    default: return ig_launch<512, 128, 4, 2, 64>(p, (hipStream_t)stream);
   }
 }
 
