@@ -158,7 +158,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    _log("warmup (first step compiles the MIOpen kernels)")
+    _log("warmup")
     for _ in range(args.warmup):
         step()
     sync()
@@ -214,7 +214,12 @@ def main():
                        "hypotheses_per_gpu": N, "refine_iterations": R,
                        "parallelism": f"object-parallel x{world}, one RCCL all-gather of [score|pose] records per step"},
             "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": traffic, "algorithmic_per_launch": dk["bytes"] if bound == "hbm" else dk["flops"],
+                         "traffic": traffic,
+                         "traffic_note": "HBM-side bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/) of "
+                                         "ONE representative launch of this kernel: the 256->256 3x3 conv at N=252 "
+                                         "(algorithmic 228 MB read + 206 MB written); achieved/avg_launch_ms average all "
+                                         "launches of the step" if dom == "fp_igemm_f16_fwd" else "profiles/traffic.json",
+                         "algorithmic_per_launch": dk["bytes"] if bound == "hbm" else dk["flops"],
                          "avg_launch_ms": dk["avg_ms"], "launches_timed": dk["calls"]},
             "stage_raster_crop": {"bytes_per_pass": stage_bytes, "ms_per_pass": r_ms + w_ms,
                                   "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,

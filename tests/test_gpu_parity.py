@@ -631,3 +631,28 @@ def test_scorer_single_hypothesis_and_fp16_ranking(scene, dev, gmesh, frame):
     assert np.abs(s16 - ref).max() < 0.25 * max(1.0, ref.std())      # fp16 deployment vs fp32 oracle
     top = np.argsort(-ref)[:3]
     assert np.argmax(s16) in top                                       # the fp16 winner is among the oracle's top 3
+
+
+# ------------------------------------------------------------------ demo driver on the on-disk formats
+def test_run_demo_on_a_synthetic_sequence(tmp_path, dev):
+    """scripts/run_demo.py: OBJ + PNG sequence written to disk, read back, register + track_one, poses on disk;
+    graph replay of track_one gives the same files"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_demo", os.path.join(root, "scripts", "run_demo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for graph in (False, True):
+        d = str(tmp_path / f"dbg{int(graph)}")
+        mod.main(["--synthetic", "3", "--est_refine_iter", "2", "--track_refine_iter", "1", "--debug_dir", d] +
+                 (["--track_graph"] if graph else []))
+        files = sorted(os.listdir(os.path.join(d, "ob_in_cam")))
+        assert files == ["0000000.txt", "0000001.txt", "0000002.txt"]
+        out[graph] = np.stack([np.loadtxt(os.path.join(d, "ob_in_cam", f)) for f in files])
+        assert np.isfinite(out[graph]).all() and np.allclose(out[graph][:, 3], [0, 0, 0, 1])
+    assert np.array_equal(out[False], out[True])
+    from foundationpose_amd.datareader import YcbineoatReader
+    r = YcbineoatReader(str(tmp_path / "dbg0" / "synthetic_scene"))
+    assert r.get_xyz_map(0).shape == (480, 640, 3)

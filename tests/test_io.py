@@ -1,0 +1,58 @@
+"""On-disk formats either side of the path: OBJ meshes and demo-format RGB-D sequences."""
+import numpy as np
+
+
+def test_obj_round_trip(tmp_path):
+    from foundationpose_amd.mesh import make_can_mesh
+    from foundationpose_amd.mesh_io import load_mesh, save_obj
+    for textured in (True, False):
+        mesh = make_can_mesh(n_ang=12, n_axial=5, textured=textured, tex_size=32)
+        path = str(tmp_path / f"can{int(textured)}.obj")
+        save_obj(mesh, path)
+        back = load_mesh(path)
+        assert back.faces.shape == mesh.faces.shape
+        # the loader merges (v, vt) pairs: same triangles in space, possibly renumbered
+        tri_a = np.sort(mesh.vertices[mesh.faces].reshape(len(mesh.faces), -1), axis=1)
+        tri_b = np.sort(back.vertices[back.faces].reshape(len(back.faces), -1), axis=1)
+        np.testing.assert_allclose(tri_a, tri_b, rtol=0, atol=1e-8)
+        if textured:
+            assert back.visual.uv is not None and np.asarray(back.visual.material.image).shape == (32, 32, 3)
+            assert np.array_equal(np.asarray(back.visual.material.image), np.asarray(mesh.visual.material.image)[..., :3])
+            ua = mesh.visual.uv[mesh.faces].reshape(len(mesh.faces), -1)
+            ub = back.visual.uv[back.faces].reshape(len(back.faces), -1)
+            np.testing.assert_allclose(ua, ub, atol=1e-8)       # per-corner texture coordinates survive
+        else:
+            assert getattr(back.visual, "uv", None) is None
+        np.testing.assert_allclose(np.linalg.norm(back.vertex_normals, axis=1), 1.0, atol=1e-6)
+
+
+def test_obj_quads_negative_indices_and_mtl_colour(tmp_path):
+    from foundationpose_amd.mesh_io import load_obj
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1.0 0.5 0.0\n")
+    (tmp_path / "q.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf -4 -3 -2 -1\n")
+    m = load_obj(str(tmp_path / "q.obj"))
+    assert m.faces.shape == (2, 3) and m.vertices.shape == (4, 3)
+    assert np.array_equal(np.asarray(m.visual.vertex_colors)[0, :3], [255, 127, 0])
+    n = m.vertex_normals
+    assert np.allclose(np.abs(n[:, 2]), 1.0)
+
+
+def test_sequence_round_trip(tmp_path, scene):
+    from foundationpose_amd.datareader import YcbineoatReader, write_sequence
+    d = str(tmp_path / "seq")
+    depth2 = scene["depth"] + 0.01
+    write_sequence(d, scene["K"], [scene["rgb"], scene["rgb"][::-1]], [scene["depth"], depth2], [scene["mask"], scene["mask"]],
+                   gt_poses=[scene["gt"], scene["gt"]])
+    r = YcbineoatReader(d, zfar=1.0)
+    assert len(r) == 2 and r.id_strs == ["0000000", "0000001"] and (r.H, r.W) == (480, 640)
+    np.testing.assert_allclose(r.K, scene["K"])
+    assert np.array_equal(r.get_color(0), scene["rgb"]) and np.array_equal(r.get_color(1), scene["rgb"][::-1])
+    assert np.array_equal(r.get_mask(0), (scene["mask"] > 0).astype(np.uint8))
+    dep = r.get_depth(0)
+    ok = (scene["depth"] >= 0.001) & (scene["depth"] < 0.9995)
+    assert np.abs(dep[ok] - scene["depth"][ok]).max() <= 0.5e-3 + 1e-9          # uint16 millimetres
+    assert (dep[scene["depth"] >= 1.0005] == 0).all()                            # zfar
+    np.testing.assert_allclose(r.get_gt_pose(1), scene["gt"], atol=1e-12)
+    half = YcbineoatReader(d, shorter_side=240)
+    assert (half.H, half.W) == (240, 320) and np.isclose(half.K[0, 0], scene["K"][0, 0] / 2)
+    assert np.array_equal(half.get_color(0), scene["rgb"][::2, ::2])
