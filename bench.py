@@ -122,9 +122,11 @@ def main():
     import torch.distributed as dist
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FP_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from foundationpose_amd import ops
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
@@ -154,7 +156,7 @@ def main():
         return gather_object_records(s[ids], p[ids])  # ONE RCCL all-gather of [score|pose] per register()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +173,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     assert torch.isfinite(rec).all()
@@ -233,7 +235,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

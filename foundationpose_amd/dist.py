@@ -95,7 +95,7 @@ def gather_object_records(scores, poses, group=None):
     returns (world, N, 17) on every rank with ONE all-gather."""
     world, _ = _world(group)
     rec = torch.cat([scores.reshape(-1, 1).float(), poses.reshape(-1, 16).float()], dim=1).contiguous()
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return rec[None]
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec, group=group)  # concatenated along dim 0 (same form on RCCL and gloo)
