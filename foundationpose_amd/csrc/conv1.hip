@@ -1,8 +1,10 @@
 // Patch-embed convolution of both encoders (refine_network.py:38, score_network.py:37: ConvBNReLU(6 -> 64, 7x7,
 // stride 2, pad 3)) for gfx950, NHWC output.  HBM-bound by construction (0.48 GFLOP against 1.95 MB per pair of
 // images), so the kernel is organised around streaming:
-//   * persistent workgroups (one per CU): the 64 x 294 weights are loaded ONCE per workgroup, straight from the
-//     PyTorch (64, 6*7*7) layout, into MFMA A-fragments that live in registers for the whole launch
+//   * persistent workgroups (one per CU, 8 waves): wave w owns output channels 32*(w&1)..+32 and every fourth pixel tile;
+//     its 32 x 294 weights are loaded ONCE, straight from the PyTorch (64, 6*7*7) layout, into MFMA A-fragments that
+//     live in registers for the whole launch (84 VGPRs, so two waves fit per SIMD and overlap each other's LDS reads,
+//     epilogue and MFMAs; the first version kept all 64 channels in one wave: 337 registers, one wave per SIMD)
 //     (k re-ordered as (c, ky, kx[8]) = 42 groups of 8 -> 21 k-steps of v_mfma_f32_32x32x16_f16; kx = 7 is a zero weight);
 //   * work unit = (image, band of 8 output rows): its 6 x 21 x (W+16) input patch goes HBM -> LDS by
 //     global_load_lds_dwordx4 (zero padding comes from a 16-byte zero block, so the DMA stays lane-linear), double
@@ -23,7 +25,7 @@ typedef unsigned int uint4_ __attribute__((ext_vector_type(4)));
 #define C1_ROWS 8                    // output rows per band
 #define C1_PR (2 * C1_ROWS + 5)      // input rows per band
 #define C1_KS 21                     // k-steps of 16 = 42 (c, ky) groups of 8 kx
-#define C1_THREADS 256
+#define C1_THREADS 512
 #define C1_MAXW 256
 
 __device__ __attribute__((aligned(16))) const unsigned int c1_zero16[4] = {0u, 0u, 0u, 0u};
@@ -62,40 +64,37 @@ __device__ __forceinline__ void c1_stage(const Conv1Params& p, int band, unsigne
   }
 }
 
-__global__ __launch_bounds__(C1_THREADS, 1) void k_conv7x7s2_nhwc(Conv1Params p) {
+__global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int px = lane & 31, kh = lane >> 5;
+  const int hsel = wid & 1;            // channel half of this wave
+  const int tslot = wid >> 1;          // pixel-tile slot 0..3
   const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;  // DMA may overrun by < 64 chunks
   unsigned char* patch0 = smem;
   unsigned char* patch1 = smem + patch_bytes;
-  unsigned char* etile = smem + 2 * patch_bytes + wid * 4096;   // wave-private 32 px x 64 ch transpose tile
+  unsigned char* etile = smem + 2 * patch_bytes + wid * 2048;   // wave-private 32 px x 32 ch transpose tile
 
-  // ---- weights -> register-resident A fragments: wf[ks][h] = W[h*32 + px][group 2*ks + kh][0..7]
-  half8 wf[C1_KS][2];
+  // ---- weights -> register-resident A fragments: wf[ks] = W[hsel*32 + px][group 2*ks + kh][0..7]
+  half8 wf[C1_KS];
 #pragma unroll
   for (int ks = 0; ks < C1_KS; ++ks) {
     const int g = 2 * ks + kh;          // (c, ky) group
+    const _Float16* w = p.W + (size_t)(hsel * 32 + px) * 294 + g * 7;   // c*49 + ky*7 == g*7
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const _Float16* w = p.W + (size_t)(h * 32 + px) * 294 + g * 7;   // c*49 + ky*7 == g*7
-#pragma unroll
-      for (int e = 0; e < 7; ++e) wf[ks][h][e] = w[e];
-      wf[ks][h][7] = (_Float16)0.f;
-    }
+    for (int e = 0; e < 7; ++e) wf[ks][e] = w[e];
+    wf[ks][7] = (_Float16)0.f;
   }
-  // BN scale / shift of this lane's 32 output channels: channel = h*32 + 8*g4 + 4*kh + e
-  float sc[2][4][4], sh[2][4][4];
+  // BN scale / shift of this lane's 16 output channels: channel = hsel*32 + 8*g4 + 4*kh + e
+  float sc[4][4], sh[4][4];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int chn = h * 32 + 8 * g4 + 4 * kh + e;
-        sc[h][g4][e] = p.scale[chn];
-        sh[h][g4][e] = p.shift[chn];
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int chn = hsel * 32 + 8 * g4 + 4 * kh + e;
+      sc[g4][e] = p.scale[chn];
+      sh[g4][e] = p.shift[chn];
+    }
 
   const int band_px = C1_ROWS * p.Wout;
   const int tiles = (band_px + 31) >> 5;
@@ -113,15 +112,15 @@ __global__ __launch_bounds__(C1_THREADS, 1) void k_conv7x7s2_nhwc(Conv1Params p)
     if (nxt < p.total_bands) c1_stage(p, nxt, cur ? patch0 : patch1, tid);
     const int b = band / p.bands_per_image;
     const int oy0 = (band - b * p.bands_per_image) * C1_ROWS;
-    for (int tile = wid; tile < tiles; tile += 4) {
+    for (int tile = tslot; tile < tiles; tile += 4) {
       int t = tile * 32 + px;
       t = t < band_px ? t : band_px - 1;
       const int oyl = t / p.Wout, ox = t - oyl * p.Wout;
       // lane base: row 2*oyl of channel 0, dword (ox + 2) of the row  [element 2*ox + 5 = image x 2*ox - 3]
       const unsigned char* lb = patch + (size_t)(2 * oyl) * row_bytes + (ox + 2) * 4;
-      float16_ acc0, acc1;
+      float16_ acc;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C1_KS; ++ks) {
         // group g = 2*ks + kh -> (c, ky) = (g / 7, g % 7); both candidates are compile-time constants
@@ -135,37 +134,30 @@ __global__ __launch_bounds__(C1_THREADS, 1) void k_conv7x7s2_nhwc(Conv1Params p)
         fv[2] = __builtin_amdgcn_alignbit(d3, d2, 16);
         fv[3] = __builtin_amdgcn_alignbit(d4, d3, 16);
         const half8 fb = __builtin_bit_cast(half8, fv);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], fb, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][1], fb, acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], fb, acc, 0, 0, 0);
       }
-      // ---- epilogue: BN + ReLU, transpose through the wave-private tile, 16-byte stores
+      // ---- epilogue: BN + ReLU, transpose through the wave-private tile (32 px x 64 B), 16-byte stores
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int g4 = 0; g4 < 4; ++g4) {
+        half4 v;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          half4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = h ? acc1[g4 * 4 + e] : acc0[g4 * 4 + e];
-            v[e] = (_Float16)fmaxf(fmaf(a, sc[h][g4][e], sh[h][g4][e]), 0.f);
-          }
-          const int chn = h * 32 + 8 * g4 + 4 * kh;
-          const int chunk = (chn >> 3) ^ (px & 7);
-          *reinterpret_cast<half4*>(etile + px * 128 + (chunk << 4) + ((chn & 4) << 1)) = v;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)fmaxf(fmaf(acc[g4 * 4 + e], sc[g4][e], sh[g4][e]), 0.f);
+        const int chl = 8 * g4 + 4 * kh;                 // channel within this wave's 32
+        const int chunk = (chl >> 3) ^ (px & 3);
+        *reinterpret_cast<half4*>(etile + px * 64 + (chunk << 4) + ((chl & 4) << 1)) = v;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < 2; ++it) {
         const int qd = lane + 64 * it;
-        const int pl = qd >> 3, chunk = qd & 7;
+        const int pl = qd >> 2, chunk = qd & 3;
         const int tt = tile * 32 + pl;
-        const half8 v = *reinterpret_cast<const half8*>(etile + pl * 128 + ((chunk ^ (pl & 7)) << 4));
+        const half8 v = *reinterpret_cast<const half8*>(etile + pl * 64 + ((chunk ^ (pl & 3)) << 4));
         if (tt < band_px) {
           const int oyy = oy0 + tt / p.Wout, oxx = tt % p.Wout;
           if (oyy < p.Hout)
-            *reinterpret_cast<half8*>(p.Y + (((size_t)b * Hp + oyy + p.pad) * Wp + oxx + p.pad) * 64 + chunk * 8) = v;
+            *reinterpret_cast<half8*>(p.Y + (((size_t)b * Hp + oyy + p.pad) * Wp + oxx + p.pad) * 64 + hsel * 32 + chunk * 8) = v;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -182,7 +174,7 @@ int fp_conv1_nhwc_launch(const void* x, const void* w, const float* scale, const
   p.total_bands = B * p.bands_per_image;
   p.PW = Win + 16;
   const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;
-  const size_t lds = 2 * (size_t)patch_bytes + 4 * 4096;
+  const size_t lds = 2 * (size_t)patch_bytes + 8 * 2048;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
