@@ -185,6 +185,23 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   __syncthreads();   // all fragment reads done before the staging buffers become the transpose tile
 
   // ---- epilogue: accumulators (+bias) -> half -> swizzled LDS tile E[m][n] -> 16-B coalesced row stores
+  // The residual rows are requested first: their HBM latency overlaps the transposition instead of being paid
+  // eight times in sequence inside the store loop.
+  constexpr int NIT = (BM * CPR) / THREADS;
+  half8 rv[NIT];
+  long long yoff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int qd = tid + it * THREADS;
+    const int ml = qd / CPR, ch = qd % CPR;
+    const int m = m0 + ml;
+    yoff[it] = -1;
+    if (m < p.M) {
+      const int n = n0 + ch * 8;
+      yoff[it] = ig_row_off(p.out, m) + n;
+      if (p.R) rv[it] = *reinterpret_cast<const half8*>(p.R + ig_row_off(p.res, m) + n);
+    }
+  }
   // D[i = channel][j = pixel]: lane holds pixel (lane & 31), channels 8g + 4*(lane>>5) + {0..3}, g = reg >> 2
   unsigned char* E = smem;   // BM rows x (2*BN) B, low 4 bits of the chunk index XORed with (m & 15)
 #pragma unroll
@@ -210,23 +227,20 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < (BM * CPR) / THREADS; ++it) {
+  for (int it = 0; it < NIT; ++it) {
+    if (yoff[it] < 0) continue;
     const int qd = tid + it * THREADS;
     const int ml = qd / CPR, ch = qd % CPR;
-    const int m = m0 + ml;
-    if (m >= p.M) continue;
     half8 v = *reinterpret_cast<const half8*>(E + ml * (2 * BN) + ((ch ^ (ml & 15)) << 4));
-    const int n = n0 + ch * 8;
     if (p.R) {
-      const half8 rv = *reinterpret_cast<const half8*>(p.R + ig_row_off(p.res, m) + n);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)rv[e]);
+      for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)rv[it][e]);
     }
     if (p.relu) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] > (_Float16)0.f ? v[e] : (_Float16)0.f;
     }
-    *reinterpret_cast<half8*>(p.Y + ig_row_off(p.out, m) + n) = v;
+    *reinterpret_cast<half8*>(p.Y + yoff[it]) = v;
   }
 }
 
