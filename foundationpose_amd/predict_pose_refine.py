@@ -49,10 +49,10 @@ def load_run(run_name, weights_root=None):
 
 
 def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_ratio, xyz_map, normal_map=None,
-                         mesh_diameter=None, cfg=None, glctx=None, mesh_tensors=None, dataset=None, AB=None):
+                         mesh_diameter=None, cfg=None, glctx=None, mesh_tensors=None, dataset=None, AB=None, depth_hw=None):
     """Reference: predict_pose_refine.py:26-89.  Returns a BatchPoseData whose rgbAs/xyz_mapAs/rgbBs/xyz_mapBs are
     views into one (2N,6,h,w) network-input buffer (``batch.AB``): A = rendered hypothesis, B = observed crop."""
-    H, W = depth.shape[:2]
+    H, W = depth_hw if depth is None else depth.shape[:2]
     handle = get_mesh_handle(mesh_tensors)
     poseA = torch.as_tensor(ob_in_cams, dtype=torch.float, device=handle.device).reshape(-1, 4, 4).contiguous()
     N = poseA.shape[0]
@@ -175,5 +175,16 @@ class PoseRefinePredictor:
         self.last_trans_update = trans
         self.last_rot_update = rot
         if get_vis:
-            logging.info("get_vis canvases are not implemented (debug-only path, SURVEY 8(f) rank 4)")
+            # debug canvas (predict_pose_refine.py:241-291): network inputs at the initial poses above those at the refined poses
+            from .vis import crop_rows_canvas, make_grid_image
+            P_in = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous()
+            canv = []
+            for P in (P_in, B_in_cams):
+                AB = torch.empty((2 * P.shape[0], 6, int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])),
+                                 dtype=torch.float32, device=dev)
+                b = make_crop_data_batch(self.cfg["input_resize"], P, mesh, rgb_t, None, K, self.cfg["crop_ratio"], xyz_t, cfg=self.cfg,
+                                         mesh_tensors=mesh_tensors, mesh_diameter=mesh_diameter, AB=AB, depth_hw=(H, W))
+                n = P.shape[0]
+                canv.append(crop_rows_canvas(b.AB[:n].cpu().numpy(), b.AB[n:].cpu().numpy()))
+            return B_in_cams, make_grid_image(canv, nrow=2, padding=2, pad_value=255)
         return B_in_cams, None

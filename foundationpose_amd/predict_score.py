@@ -106,5 +106,8 @@ class ScorePredictor:
         logits = plan.head(feats, L=feats.shape[0]).reshape(-1)
         scores = logits + 100  # predict_score.py:209
         if get_vis:
-            logging.info("get_vis canvases are not implemented (debug-only path, SURVEY 8(f) rank 4)")
+            # debug canvas (predict_score.py:27-52, :219-223): the crops of all hypotheses, best score first
+            from .vis import crop_rows_canvas
+            ids = scores.argsort(descending=True).cpu().numpy()
+            return scores, crop_rows_canvas(batch.AB[:N].float().cpu().numpy(), batch.AB[N:].float().cpu().numpy(), ids=ids)
         return scores, None

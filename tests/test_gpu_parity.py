@@ -656,3 +656,24 @@ def test_run_demo_on_a_synthetic_sequence(tmp_path, dev):
     from foundationpose_amd.datareader import YcbineoatReader
     r = YcbineoatReader(str(tmp_path / "dbg0" / "synthetic_scene"))
     assert r.get_xyz_map(0).shape == (480, 640, 3)
+
+
+def test_get_vis_canvases(scene, dev, gmesh, frame):
+    """get_vis=True returns the debug canvases of predict_pose_refine.py:241-291 / predict_score.py:219-223 and leaves
+    the numeric result untouched"""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    P0 = scene["poses"][::64]
+    n = len(P0)
+    refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev)
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    o0, v0 = refiner.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], iteration=1, **kw)
+    o1, v1 = refiner.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], iteration=1, get_vis=True, **kw)
+    assert v0 is None and torch.equal(o0, o1)
+    assert v1.dtype == np.uint8 and v1.ndim == 3 and v1.shape[0] > n * 160 and v1.shape[1] > 2 * 4 * 160
+    assert v1.std() > 5      # rendered + observed content, not a blank sheet
+    scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), device=dev)
+    s0, _ = scorer.predict(scene["rgb"], frame["depth_t"], scene["K"], o0, **kw)
+    s1, v2 = scorer.predict(scene["rgb"], frame["depth_t"], scene["K"], o0, get_vis=True, **kw)
+    assert torch.equal(s0, s1) and v2.dtype == np.uint8 and v2.shape[0] > n * 160 and v2.shape[1] > 4 * 160

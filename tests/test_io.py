@@ -56,3 +56,32 @@ def test_sequence_round_trip(tmp_path, scene):
     half = YcbineoatReader(d, shorter_side=240)
     assert (half.H, half.W) == (240, 320) and np.isclose(half.K[0, 0], scene["K"][0, 0] / 2)
     assert np.array_equal(half.get_color(0), scene["rgb"][::2, ::2])
+
+
+def test_metrics_and_debug_drawing(scene):
+    from foundationpose_amd import vis
+    pts = np.asarray(scene["mesh"].vertices)
+    gt = scene["gt"]
+    moved = gt.copy()
+    moved[:3, 3] += [0.01, 0, 0]
+    assert abs(vis.add_err(moved, gt, pts) - 0.01) < 1e-9 and vis.add_err(gt, gt, pts) == 0
+    assert 0 < vis.adds_err(moved, gt, pts) <= 0.01 + 1e-9
+    # a half-turn about the can's axis is invisible to ADD-S (symmetric point set) but not to ADD
+    flip = gt @ np.diag([-1.0, -1.0, 1.0, 1.0])
+    assert vis.adds_err(flip, gt, pts) < 1e-3 < vis.add_err(flip, gt, pts)
+    assert abs(vis.compute_auc([0.0] * 10) - 1.0) < 1e-9 and vis.compute_auc([1.0] * 10) == 0.0
+    assert 0.45 < vis.compute_auc(np.linspace(0, 0.1, 101)) < 0.55
+    dv = vis.depth_to_vis(scene["depth"], inverse=True)
+    assert dv.shape == (480, 640, 3) and dv.dtype == np.uint8
+    g = vis.make_grid_image([np.zeros((10, 12, 3)), np.ones((10, 12, 3)) * 200, np.zeros((10, 12, 3))], nrow=2, padding=2)
+    assert g.shape == (2 * 12 + 2, 2 * 14 + 2, 3) and g[0, 0, 0] == 255 and g[2, 16, 0] == 200
+    box = np.stack([pts.min(0), pts.max(0)])
+    img = vis.draw_posed_3d_box(scene["K"], scene["rgb"], gt, box)
+    img = vis.draw_xyz_axis(img, gt, scale=0.1, K=scene["K"])
+    assert img.shape == scene["rgb"].shape and (img != scene["rgb"]).any()
+    ys, xs = np.nonzero((img != scene["rgb"]).any(-1))
+    m = np.nonzero(scene["mask"])
+    assert xs.min() >= m[1].min() - 80 and xs.max() <= m[1].max() + 80      # the overlay sits on the object
+    A = np.random.default_rng(0).random((3, 6, 16, 16)).astype(np.float32)
+    c = vis.crop_rows_canvas(A, A)
+    assert c.ndim == 3 and c.shape[2] == 3 and c.shape[0] > 3 * 16
