@@ -27,8 +27,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include "igemm_common.h"
+#include "igemm_epilogue.h"
 
 int fp_conv3x3s1_launch(const IgemmParams& p, int B, hipStream_t stream);   // conv3x3.hip
+int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream);   // igemm_pp.hip
 
 // Workgroup tile BM (pixels) x BN (channels) x 64 (k); every wave owns (32*TM) x 64 outputs as TM x 2
 // v_mfma_f32_32x32x16_f16 tiles; NST LDS stages (prefetch distance NST-1 k-steps, counted vmcnt + raw s_barrier).
@@ -54,7 +56,6 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   // the 256-byte bank row, which holds 2 rows at BK=64 and 4 rows at BK=32
   auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   constexpr int LPS = AI + WI;
-  constexpr int CPR = BN / 8;                      // 16-byte chunks per row of the epilogue tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
@@ -184,70 +185,13 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   }
   __syncthreads();   // all fragment reads done before the staging buffers become the transpose tile
 
-  // ---- epilogue: accumulators (+bias) -> half -> swizzled LDS tile E[m][n] -> 16-B coalesced row stores
-  // The residual rows are requested first: their HBM latency overlaps the transposition instead of being paid
-  // eight times in sequence inside the store loop.
-  constexpr int NIT = (BM * CPR) / THREADS;
-  half8 rv[NIT];
-  long long yoff[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int qd = tid + it * THREADS;
-    const int ml = qd / CPR, ch = qd % CPR;
-    const int m = m0 + ml;
-    yoff[it] = -1;
-    if (m < p.M) {
-      const int n = n0 + ch * 8;
-      yoff[it] = ig_row_off(p.out, m) + n;
-      if (p.R) rv[it] = *reinterpret_cast<const half8*>(p.R + ig_row_off(p.res, m) + n);
-    }
-  }
-  // D[i = channel][j = pixel]: lane holds pixel (lane & 31), channels 8g + 4*(lane>>5) + {0..3}, g = reg >> 2
-  unsigned char* E = smem;   // BM rows x (2*BN) B, low 4 bits of the chunk index XORed with (m & 15)
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);   // first of 4 consecutive channels (tile-local)
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = p.bias[n0 + nl + e];
-      }
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int ml = wm * (32 * TM) + j * 32 + (lane & 31);
-        half4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
-        const int chunk = (nl >> 3) ^ (ml & 15);
-        *reinterpret_cast<half4*>(E + ml * (2 * BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    if (yoff[it] < 0) continue;
-    const int qd = tid + it * THREADS;
-    const int ml = qd / CPR, ch = qd % CPR;
-    half8 v = *reinterpret_cast<const half8*>(E + ml * (2 * BN) + ((ch ^ (ml & 15)) << 4));
-    if (p.R) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)rv[it][e]);
-    }
-    if (p.relu) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] > (_Float16)0.f ? v[e] : (_Float16)0.f;
-    }
-    *reinterpret_cast<half8*>(p.Y + yoff[it]) = v;
-  }
+  ig_epilogue<BM, BN, TM, THREADS>(p, acc, smem, m0, n0, wm, wn, tid, lane);
 }
 
 template <int BM, int BN, int TM, int NST, int BK>
 static int ig_launch(const IgemmParams& p, hipStream_t stream) {
   constexpr int STAGES = NST * (BM + BN) * BK * 2;
-  constexpr int ETILE = BM * BN * 2;
+  constexpr int ETILE = BM * BN * 2 + BM * 16;   // + the row-offset tables of the epilogue
   constexpr int LDS = STAGES > ETILE ? STAGES : ETILE;
   constexpr int THREADS = (BM / (32 * TM)) * (BN / 64) * 64;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
@@ -323,6 +267,9 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
       else if (!strcmp(e, "512x128")) forced = 4;
       else if (!strcmp(e, "128x128k32x3")) forced = 5;
       else if (!strcmp(e, "128x128k32x4")) forced = 6;
+      else if (!strcmp(e, "pp256x256")) forced = 7;
+      else if (!strcmp(e, "pp512x128")) forced = 8;
+      else if (!strcmp(e, "pp256x128")) forced = 9;
     }
   }
   int sel = forced;
@@ -330,6 +277,8 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   // (256->256 convs 947 vs 899 TFLOP/s, QKV projection 688 vs 561), 128x128 (two workgroups per CU) elsewhere
   if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 3 : 1;
   if (sel == 3 && (N % 256) != 0) sel = 4;
+  if (sel == 7 && (N % 256) != 0) sel = 8;
+  if (sel >= 7) return fp_igemm_pp_launch(p, sel - 7, (hipStream_t)stream);
   switch (sel) {
     case 1: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
     case 2: return ig_launch<256, 128, 2, 3, 64>(p, (hipStream_t)stream);

@@ -1,0 +1,81 @@
+// Shared epilogue of the implicit-GEMM kernels (igemm.hip, igemm_pp.hip): accumulators (+bias) -> half -> swizzled LDS
+// tile E[m][n] -> 16-byte coalesced row stores with the residual add and ReLU applied on the way out.
+// Call after a workgroup barrier that retires every read of the staging buffers (the tile reuses them).
+#pragma once
+#include "igemm_common.h"
+
+// FULL: every row of the tile exists (m0 + BM <= M) -- no per-row predicate, so the LDS reads and the stores of the
+// 16 iterations are issued as batches instead of one LDS round trip after the other.
+template <int BM, int BN, int TM, int THREADS, int DBG, bool FULL>
+__device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ (&acc)[2][TM], unsigned char* smem, int m0, int n0,
+                                                 int wm, int wn, int tid, int lane) {
+  constexpr int CPR = BN / 8;                      // 16-byte chunks per row of the epilogue tile
+  constexpr int NIT = (BM * CPR) / THREADS;
+  // ---- epilogue: accumulators (+bias) -> half -> swizzled LDS tile E[m][n] -> 16-B coalesced row stores
+  // Row addressing first: ONE thread per tile row maps the row to its element offsets in the output (and residual)
+  // buffer and parks them in LDS behind the E tile; the store loop then reads them back as broadcasts.  (Computing the
+  // map per (row, 16-byte chunk), as the first version did, cost 16-32 emulated 64-bit address computations per thread
+  // and made the epilogue 20-45 % of the kernel.)
+  unsigned char* E = smem;   // BM rows x (2*BN) B, low 4 bits of the chunk index XORed with (m & 15)
+  long long* rowY = reinterpret_cast<long long*>(smem + BM * 2 * BN);
+  long long* rowR = rowY + BM;
+  for (int r = tid; r < BM; r += THREADS) {
+    const int m = m0 + r;
+    const bool in = m < p.M;
+    rowY[r] = in ? ig_row_off(p.out, m) + n0 : -1;
+    if (p.R) rowR[r] = in ? ig_row_off(p.res, m) + n0 : 0;
+  }
+  __syncthreads();
+  // The residual rows are requested before the transposition: their HBM latency overlaps it
+  half8 rv[NIT];
+  if (p.R) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int qd = tid + it * THREADS;
+      const int ml = qd / CPR, ch = qd % CPR;
+      if (FULL || rowY[ml] >= 0) rv[it] = *reinterpret_cast<const half8*>(p.R + rowR[ml] + ch * 8);
+    }
+  }
+  // D[i = channel][j = pixel]: lane holds pixel (lane & 31), channels 8g + 4*(lane>>5) + {0..3}, g = reg >> 2
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);   // first of 4 consecutive channels (tile-local)
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = p.bias[n0 + nl + e];
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int ml = wm * (32 * TM) + j * 32 + (lane & 31);
+        half4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
+        const int chunk = (nl >> 3) ^ (ml & 15);
+        *reinterpret_cast<half4*>(E + ml * (2 * BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
+      }
+    }
+  }
+  __syncthreads();
+  const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int qd = tid + it * THREADS;
+    const int ml = qd / CPR, ch = qd % CPR;
+    const long long yo = rowY[ml];
+    if (!FULL && yo < 0) continue;
+    half8 v = *reinterpret_cast<const half8*>(E + ml * (2 * BN) + ((ch ^ (ml & 15)) << 4));
+    if (p.R) v = v + rv[it];                       // IEEE half add == the fp32 add of two halves rounded once
+    if (p.relu) v = __builtin_elementwise_max(v, zero);
+    if (DBG != 8 || v[0] == (_Float16)12345.f) *reinterpret_cast<half8*>(p.Y + yo + ch * 8) = v;   // DBG 8: timing without the store tail
+  }
+}
+
+template <int BM, int BN, int TM, int THREADS, int DBG = 0>
+__device__ __forceinline__ void ig_epilogue(const IgemmParams& p, float16_ (&acc)[2][TM], unsigned char* smem, int m0, int n0,
+                                            int wm, int wn, int tid, int lane) {
+  if (m0 + BM <= p.M) ig_epilogue_body<BM, BN, TM, THREADS, DBG, true>(p, acc, smem, m0, n0, wm, wn, tid, lane);
+  else ig_epilogue_body<BM, BN, TM, THREADS, DBG, false>(p, acc, smem, m0, n0, wm, wn, tid, lane);
+}

@@ -40,6 +40,8 @@ for M, K, No in [(N * 400, 512, 1536), (N * 400, 512, 512)]:
     print(f"igemm linear M={M} K={K} N={No}: {ms:.3f} ms  {2.0 * M * K * No / ms / 1e9:.0f} TFLOP/s", flush=True)
     ms = timeit(lambda: torch.nn.functional.linear(x, w, b.half()))
     print(f"torch  linear M={M} K={K} N={No}: {ms:.3f} ms  {2.0 * M * K * No / ms / 1e9:.0f} TFLOP/s", flush=True)
+if os.environ.get('FP_LAYERS_ONLY'):
+    sys.exit(0)
 # whole encoder + plan
 from foundationpose_amd import engine
 from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
