@@ -56,10 +56,12 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   // the 256-byte bank row, which holds 2 rows at BK=64 and 4 rows at BK=32
   auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
   constexpr int LPS = AI + WI;
+  constexpr int LDS_MAIN = ig_lds_main<BM, BN>(NST * STAGE_BYTES);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it in an SGPR
   const int wm = wid / NWN, wn = wid - wm * NWN;   // wave position: pixels (m) x channels (n)
+  float* bias_lds = reinterpret_cast<float*>(smem + LDS_MAIN);
 
   // ---- XCD-aware tile order (bijective for any grid size)
   const int tiles_n = p.N / BN;
@@ -70,6 +72,7 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
+  ig_bias_to_lds(p, n0, bias_lds, wid, lane);
 
   // ---- per-thread staging sources: wave w loads rows [8*AI*w, +8*AI) of the A tile and [8*WI*w, +8*WI) of the W tile.
   // Kept as 32-bit byte offsets from the (uniform) tensor bases, so that the per-k-step part of every address is a
@@ -185,14 +188,12 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   }
   __syncthreads();   // all fragment reads done before the staging buffers become the transpose tile
 
-  ig_epilogue<BM, BN, TM, THREADS>(p, acc, smem, m0, n0, wm, wn, tid, lane);
+  ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
 }
 
 template <int BM, int BN, int TM, int NST, int BK>
 static int ig_launch(const IgemmParams& p, hipStream_t stream) {
-  constexpr int STAGES = NST * (BM + BN) * BK * 2;
-  constexpr int ETILE = BM * BN * 2 + BM * 16;   // + the row-offset tables of the epilogue
-  constexpr int LDS = STAGES > ETILE ? STAGES : ETILE;
+  constexpr int LDS = ig_lds_main<BM, BN>(NST * (BM + BN) * BK * 2) + IG_BIAS_LDS;
   constexpr int THREADS = (BM / (32 * TM)) * (BN / 64) * 64;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
@@ -237,6 +238,8 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
   FP_REQUIRE(Cin > 0 && Cin % 64 == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of 64", Cin);
   FP_REQUIRE(!residual || r_geom, "fp_igemm_f16_fwd: residual without geometry");
+  FP_REQUIRE((((size_t)x | (size_t)w | (size_t)y | (size_t)residual | (size_t)bias) & 15) == 0,
+             "fp_igemm_f16_fwd: tensors must be 16-byte aligned");
   if (int e = ig_check_geom(x_geom, "input")) return e;
   if (int e = ig_check_geom(y_geom, "output")) return e;
   if (residual) if (int e = ig_check_geom(r_geom, "residual")) return e;
@@ -255,7 +258,7 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
       M % p.in.HoWo == 0 && M >= 1024 && p.out.HoWo == p.in.HoWo && p.out.Wo == p.in.Wo && p.out.stride == 1 &&
       (!residual || (p.res.HoWo == p.in.HoWo && p.res.Wo == p.in.Wo && p.res.stride == 1)))
     return fp_conv3x3s1_launch(p, M / p.in.HoWo, (hipStream_t)stream);
-  // tile selection; FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | 512x128 forces one (profiling aid)
+  // tile selection; FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | pp256x256 | pp256x128 ... forces one (profiling aid)
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("FP_IGEMM_TILE");
@@ -264,20 +267,19 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
       if (!strcmp(e, "128x128")) forced = 1;
       else if (!strcmp(e, "256x128")) forced = 2;
       else if (!strcmp(e, "256x256")) forced = 3;
-      else if (!strcmp(e, "512x128")) forced = 4;
       else if (!strcmp(e, "128x128k32x3")) forced = 5;
       else if (!strcmp(e, "128x128k32x4")) forced = 6;
       else if (!strcmp(e, "pp256x256")) forced = 7;
-      else if (!strcmp(e, "pp512x128")) forced = 8;
       else if (!strcmp(e, "pp256x128")) forced = 9;
+      else if (!strcmp(e, "ppr256x256")) forced = 10;
     }
   }
   int sel = forced;
   // measured at the bench shapes (scripts/bench_igemm.py): 256x256 wins where both M and N are large
   // (256->256 convs 947 vs 899 TFLOP/s, QKV projection 688 vs 561), 128x128 (two workgroups per CU) elsewhere
-  if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 3 : 1;
-  if (sel == 3 && (N % 256) != 0) sel = 4;
-  if (sel == 7 && (N % 256) != 0) sel = 8;
+  if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 7 : 1;
+  if (sel == 3 && (N % 256) != 0) sel = 2;
+  if ((sel == 7 || sel == 10) && (N % 256) != 0) sel = 9;
   if (sel >= 7) return fp_igemm_pp_launch(p, sel - 7, (hipStream_t)stream);
   switch (sel) {
     case 1: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
@@ -285,7 +287,7 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
     case 3: return ig_launch<256, 256, 4, 2, 64>(p, (hipStream_t)stream);
     case 5: return ig_launch<128, 128, 2, 3, 32>(p, (hipStream_t)stream);   // 48 KiB: three workgroups per CU
     case 6: return ig_launch<128, 128, 2, 4, 32>(p, (hipStream_t)stream);   // 64 KiB: prefetch distance 3
-    default: return ig_launch<512, 128, 4, 2, 64>(p, (hipStream_t)stream);
+    default: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
   }
 }
 

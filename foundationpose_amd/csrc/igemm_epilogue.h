@@ -1,14 +1,21 @@
 // Shared epilogue of the implicit-GEMM kernels (igemm.hip, igemm_pp.hip): accumulators (+bias) -> half -> swizzled LDS
 // tile E[m][n] -> 16-byte coalesced row stores with the residual add and ReLU applied on the way out.
 // Call after a workgroup barrier that retires every read of the staging buffers (the tile reuses them).
+// LDS layout of a kernel that uses it: [0, max(stages, E tile + row tables)) shared by the main loop and the epilogue,
+// then BN floats of bias (ig_lds_bytes).
 #pragma once
 #include "igemm_common.h"
 
 // FULL: every row of the tile exists (m0 + BM <= M) -- no per-row predicate, so the LDS reads and the stores of the
 // 16 iterations are issued as batches instead of one LDS round trip after the other.
+template <int BM, int BN>
+constexpr int ig_lds_main(int stage_bytes) {
+  return stage_bytes > BM * BN * 2 + BM * 16 ? stage_bytes : BM * BN * 2 + BM * 16;   // E tile + the two row-offset tables
+}
+
 template <int BM, int BN, int TM, int THREADS, int DBG, bool FULL>
 __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ (&acc)[2][TM], unsigned char* smem, int m0, int n0,
-                                                 int wm, int wn, int tid, int lane) {
+                                                 int wm, int wn, int tid, int lane, const float* bias_lds) {
   constexpr int CPR = BN / 8;                      // 16-byte chunks per row of the epilogue tile
   constexpr int NIT = (BM * CPR) / THREADS;
   // ---- epilogue: accumulators (+bias) -> half -> swizzled LDS tile E[m][n] -> 16-B coalesced row stores
@@ -17,6 +24,15 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
   // map per (row, 16-byte chunk), as the first version did, cost 16-32 emulated 64-bit address computations per thread
   // and made the epilogue 20-45 % of the kernel.)
   unsigned char* E = smem;   // BM rows x (2*BN) B, low 4 bits of the chunk index XORed with (m & 15)
+  // bias: staged into LDS at kernel entry (ig_bias_to_lds) -- a global load issued here would be exposed in full, and
+  // under the operand stream's load that is several thousand cycles
+  typedef float float4_ __attribute__((ext_vector_type(4)));
+  float4_ bv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bv[i][g] = *reinterpret_cast<const float4_*>(bias_lds + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5));
   long long* rowY = reinterpret_cast<long long*>(smem + BM * 2 * BN);
   long long* rowR = rowY + BM;
   for (int r = tid; r < BM; r += THREADS) {
@@ -42,17 +58,12 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nl = wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);   // first of 4 consecutive channels (tile-local)
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = p.bias[n0 + nl + e];
-      }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int ml = wm * (32 * TM) + j * 32 + (lane & 31);
         half4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[i][g][e]);
         const int chunk = (nl >> 3) ^ (ml & 15);
         *reinterpret_cast<half4*>(E + ml * (2 * BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
       }
@@ -69,13 +80,28 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
     half8 v = *reinterpret_cast<const half8*>(E + ml * (2 * BN) + ((ch ^ (ml & 15)) << 4));
     if (p.R) v = v + rv[it];                       // IEEE half add == the fp32 add of two halves rounded once
     if (p.relu) v = __builtin_elementwise_max(v, zero);
-    if (DBG != 8 || v[0] == (_Float16)12345.f) *reinterpret_cast<half8*>(p.Y + yo + ch * 8) = v;   // DBG 8: timing without the store tail
+    *reinterpret_cast<half8*>(p.Y + yo + ch * 8) = v;
   }
 }
 
 template <int BM, int BN, int TM, int THREADS, int DBG = 0>
 __device__ __forceinline__ void ig_epilogue(const IgemmParams& p, float16_ (&acc)[2][TM], unsigned char* smem, int m0, int n0,
-                                            int wm, int wn, int tid, int lane) {
-  if (m0 + BM <= p.M) ig_epilogue_body<BM, BN, TM, THREADS, DBG, true>(p, acc, smem, m0, n0, wm, wn, tid, lane);
-  else ig_epilogue_body<BM, BN, TM, THREADS, DBG, false>(p, acc, smem, m0, n0, wm, wn, tid, lane);
+                                            int wm, int wn, int tid, int lane, const float* bias_lds) {
+  if (m0 + BM <= p.M) ig_epilogue_body<BM, BN, TM, THREADS, DBG, true>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
+  else ig_epilogue_body<BM, BN, TM, THREADS, DBG, false>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
+}
+// Kernel entry, BEFORE the first operand stage is requested: wave 0 sends the tile's bias straight to LDS with one
+// LDS-DMA (1 KiB = 256 floats; reads past the end of the bias vector return 0 through the buffer descriptor's bound).
+// Being the oldest vector-memory operation of the wave it is covered by every later counted vmcnt wait, and it is
+// visible to the workgroup after the first barrier of the main loop.  The LDS area is always 1 KiB (IG_BIAS_LDS).
+#define IG_BIAS_LDS 1024
+__device__ __forceinline__ void ig_bias_to_lds(const IgemmParams& p, int n0, float* bias_lds, int wid, int lane) {
+  if (wid != 0) return;
+  if (p.bias) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)bias_lds, 16, lane * 16, n0 * 4, 0, 0);
+  } else {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<f4*>(bias_lds + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
+  }
 }

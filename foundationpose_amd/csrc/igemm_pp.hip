@@ -26,8 +26,8 @@
 
 // DBG != 0 builds timing-only variants that isolate one resource (results are wrong by construction; FP_IGEMM_DBG):
 //   1 every tile stages the A rows of tile 0 (operand stream served by L2), 2 no LDS-DMA in the main loop,
-//   3 no fragment reads in the main loop, 4 neither (MFMA + barriers only), 6 dword-wide LDS-DMA (same instruction
-//   count, a quarter of the bytes)
+//   9 no epilogue.  Measured at the bench shapes (256->256 / 512->512 conv, TFLOP/s): normal 948 / 992, (1) 1010 / 991,
+//   (2) 1272 / 1395, (9) 1185 / 1103 -- see DESIGN.md 3.2.
 template <int BM, int BN, int TM, int DBG>
 __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
   constexpr int BK = 32, NST = 4, NW = 8, THREADS = 512;
@@ -42,12 +42,14 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
   constexpr int AI = BM / RPI / NW, WI = BN / RPI / NW;
   static_assert(AI >= 1 && WI >= 1, "tile too small");
   constexpr int LPS = AI + WI;                     // LDS-DMA instructions per wave and stage
+  constexpr int LDS_MAIN = ig_lds_main<BM, BN>(NST * STAGE_BYTES);
   auto swz = [](int row) { return (row >> 2) & 3; };   // 4 rows share a 256-byte bank row (igemm.hip, BK = 32 case)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;                        // 0: leads, 1: one cluster behind
   const int wm = wid / NWN, wn = wid - wm * NWN;
+  float* bias_lds = reinterpret_cast<float*>(smem + LDS_MAIN);
 
   // XCD-aware tile order (as igemm.hip)
   const int tiles_n = p.N / BN;
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
+  ig_bias_to_lds(p, n0, bias_lds, wid, lane);
 
   unsigned aoff32[AI], woff32[WI];
 #pragma unroll
@@ -87,20 +90,12 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
     unsigned char* sw = smem + buf * STAGE_BYTES + A_BYTES + wid * (WI * 1024);
 #pragma unroll
     for (int j = 0; j < AI; ++j)
-      if constexpr (DBG == 6)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sa + j * 1024), 4,
-                                                 (int)aoff32[j], asoff, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sa + j * 1024), 16,
-                                                 (int)aoff32[j], asoff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sa + j * 1024), 16,
+                                               (int)aoff32[j], asoff, 0, 0);
 #pragma unroll
     for (int j = 0; j < WI; ++j)
-      if constexpr (DBG == 6)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sw + j * 1024), 4,
-                                                 (int)woff32[j], wsoff, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sw + j * 1024), 16,
-                                                 (int)woff32[j], wsoff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sw + j * 1024), 16,
+                                               (int)woff32[j], wsoff, 0, 0);
     ++st_k;
     st_ci0 += BK;
     if (st_ci0 == Cin) { st_ci0 = 0; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
@@ -149,7 +144,6 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
   for (int ks = 0; ks < nk; ++ks) {
     // ---- memory cluster
     const unsigned char* sb = smem + buf * STAGE_BYTES;
-    if (DBG < 3 || ks == 0)
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
@@ -157,7 +151,7 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) fw[kk][t] = *reinterpret_cast<const half8*>(sb + w_off[t][kk]);
     }
-    if (ks + NST - 1 < nk && DBG != 2 && DBG != 4) {
+    if (ks + NST - 1 < nk && DBG != 2) {
       stage(nbuf);
       wait_two_stages_in_flight();                 // own pieces of k-step ks+1 have landed
     } else {
@@ -196,14 +190,12 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
     if (sum == 12345.f) p.Y[tid] = (_Float16)1.f;
     return;
   }
-  ig_epilogue<BM, BN, TM, THREADS, DBG>(p, acc, smem, m0, n0, wm, wn, tid, lane);
+  ig_epilogue<BM, BN, TM, THREADS, DBG>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
 }
 
 template <int BM, int BN, int TM, int DBG>
 static int ig_pp_launch(const IgemmParams& p, hipStream_t stream) {
-  constexpr int STAGES = 4 * (BM + BN) * 32 * 2;
-  constexpr int ETILE = BM * BN * 2 + BM * 16;   // + the row-offset tables of the epilogue
-  constexpr int LDS = STAGES > ETILE ? STAGES : ETILE;
+  constexpr int LDS = ig_lds_main<BM, BN>(4 * (BM + BN) * 32 * 2) + IG_BIAS_LDS;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
@@ -241,6 +233,7 @@ __global__ __launch_bounds__(512, 1) void k_igemm_ppr(IgemmParams p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;
   const int wm = wid / NWN, wn = wid - wm * NWN;
+  float* bias_lds = reinterpret_cast<float*>(smem + ig_lds_main<BM, BN>(2 * STAGE_BYTES));
 
   const int tiles_n = p.N / BN;
   const int nwg = gridDim.x;
@@ -250,6 +243,7 @@ __global__ __launch_bounds__(512, 1) void k_igemm_ppr(IgemmParams p) {
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
+  ig_bias_to_lds(p, n0, bias_lds, wid, lane);
 
   unsigned aoff32[AI], woff32[WI];
 #pragma unroll
@@ -365,14 +359,12 @@ __global__ __launch_bounds__(512, 1) void k_igemm_ppr(IgemmParams p) {
   }
   if (!grp) __builtin_amdgcn_s_barrier();
   __syncthreads();
-  ig_epilogue<BM, BN, TM, THREADS>(p, acc, smem, m0, n0, wm, wn, tid, lane);
+  ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
 }
 
 template <int BM, int BN, int TM>
 static int ig_ppr_launch(const IgemmParams& p, hipStream_t stream) {
-  constexpr int STAGES = 2 * (BM + BN) * 32 * 2;
-  constexpr int ETILE = BM * BN * 2 + BM * 16;   // + the row-offset tables of the epilogue
-  constexpr int LDS = STAGES > ETILE ? STAGES : ETILE;
+  constexpr int LDS = ig_lds_main<BM, BN>(2 * (BM + BN) * 32 * 2) + IG_BIAS_LDS;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
@@ -386,7 +378,7 @@ static int ig_ppr_launch(const IgemmParams& p, hipStream_t stream) {
   return FP_OK;
 }
 
-// variant: 0 = 256x256 (N % 256 == 0), 1 = 512x128, 2 = 256x128
+// variant: 0 = 256x256 (N % 256 == 0), 3 = 256x256 register-staged, otherwise 256x128
 int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream) {
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("FP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
@@ -398,13 +390,13 @@ int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream) {
       case 6: return ig_pp_launch<256, 256, 4, 6>(p, stream);
       case 8: return ig_pp_launch<256, 256, 4, 8>(p, stream);
       case 9: return ig_pp_launch<256, 256, 4, 9>(p, stream);
+      case 10: return ig_pp_launch<256, 256, 4, 10>(p, stream);
       case 7: return ig_ppr_launch<256, 256, 4>(p, stream);
       default: return ig_pp_launch<256, 256, 4, 4>(p, stream);
     }
   }
   switch (variant) {
     case 0: return ig_pp_launch<256, 256, 4, 0>(p, stream);
-    case 1: return ig_pp_launch<512, 128, 4, 0>(p, stream);
     default: return ig_pp_launch<256, 128, 2, 0>(p, stream);
   }
 }
