@@ -31,6 +31,7 @@
 
 int fp_conv3x3s1_launch(const IgemmParams& p, int B, hipStream_t stream);   // conv3x3.hip
 int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream);   // igemm_pp.hip
+int fp_igemm_pps_launch(const IgemmParams& p, hipStream_t stream);              // igemm_pps.hip
 
 // Workgroup tile BM (pixels) x BN (channels) x 64 (k); every wave owns (32*TM) x 64 outputs as TM x 2
 // v_mfma_f32_32x32x16_f16 tiles; NST LDS stages (prefetch distance NST-1 k-steps, counted vmcnt + raw s_barrier).
@@ -272,6 +273,7 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
       else if (!strcmp(e, "pp256x256")) forced = 7;
       else if (!strcmp(e, "pp256x128")) forced = 9;
       else if (!strcmp(e, "ppr256x256")) forced = 10;
+      else if (!strcmp(e, "pps256x256")) forced = 11;
     }
   }
   int sel = forced;
@@ -279,7 +281,8 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   // (256->256 convs 947 vs 899 TFLOP/s, QKV projection 688 vs 561), 128x128 (two workgroups per CU) elsewhere
   if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 7 : 1;
   if (sel == 3 && (N % 256) != 0) sel = 2;
-  if ((sel == 7 || sel == 10) && (N % 256) != 0) sel = 9;
+  if ((sel == 7 || sel == 10 || sel == 11) && (N % 256) != 0) sel = 9;
+  if (sel == 11) return fp_igemm_pps_launch(p, (hipStream_t)stream);
   if (sel >= 7) return fp_igemm_pp_launch(p, sel - 7, (hipStream_t)stream);
   switch (sel) {
     case 1: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
