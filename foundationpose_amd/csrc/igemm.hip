@@ -31,14 +31,12 @@
 
 int fp_conv3x3s1_launch(const IgemmParams& p, int B, hipStream_t stream);   // conv3x3.hip
 int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream);   // igemm_pp.hip
-int fp_igemm_pps_launch(const IgemmParams& p, hipStream_t stream);              // igemm_pps.hip
 
 // Workgroup tile BM (pixels) x BN (channels) x 64 (k); every wave owns (32*TM) x 64 outputs as TM x 2
 // v_mfma_f32_32x32x16_f16 tiles; NST LDS stages (prefetch distance NST-1 k-steps, counted vmcnt + raw s_barrier).
-// Measured at the bench shapes: the 2x2-tile variants (128x128x2st, 256x128x3st, ...) all sit at 0.65-0.87 PFLOP/s
-// regardless of prefetch depth -- they are bound by the issue cost of their own LDS-DMA (6-8 global_load_lds per
-// wave against 16 MFMAs per k-step), so the lever is FLOP per staged byte: 4x2 tiles per wave in a 256x256 or
-// 512x128 workgroup tile halve the DMA instructions per MFMA and cut the fragment reads per MFMA by 25 %.
+// Measured at the bench shapes: the throughput follows the operand bytes per flop, not the schedule --
+// 4x2 MFMA tiles per wave (256x256 workgroup tile) halve the staged bytes per MFMA against 2x2 (128x128), and the
+// 128x128 variant makes up for it with two co-resident workgroups that fill each other's barrier and epilogue gaps.
 template <int BM, int BN, int TM, int NST, int BK>
 __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_f16(IgemmParams p) {
   constexpr int NWN = BN / 64;
@@ -273,16 +271,14 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
       else if (!strcmp(e, "pp256x256")) forced = 7;
       else if (!strcmp(e, "pp256x128")) forced = 9;
       else if (!strcmp(e, "ppr256x256")) forced = 10;
-      else if (!strcmp(e, "pps256x256")) forced = 11;
     }
   }
   int sel = forced;
-  // measured at the bench shapes (scripts/bench_igemm.py): 256x256 wins where both M and N are large
-  // (256->256 convs 947 vs 899 TFLOP/s, QKV projection 688 vs 561), 128x128 (two workgroups per CU) elsewhere
+  // measured at the bench shapes (scripts/bench_igemm.py): the 256x256 ping-pong kernel wins where both M and N are
+  // large (256->256 convs 1026 vs 917 TFLOP/s, QKV projection 767 vs 571), 128x128 (two workgroups per CU) elsewhere
   if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 7 : 1;
   if (sel == 3 && (N % 256) != 0) sel = 2;
-  if ((sel == 7 || sel == 10 || sel == 11) && (N % 256) != 0) sel = 9;
-  if (sel == 11) return fp_igemm_pps_launch(p, (hipStream_t)stream);
+  if ((sel == 7 || sel == 10) && (N % 256) != 0) sel = 9;
   if (sel >= 7) return fp_igemm_pp_launch(p, sel - 7, (hipStream_t)stream);
   switch (sel) {
     case 1: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);

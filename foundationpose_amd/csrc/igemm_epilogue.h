@@ -1,8 +1,8 @@
 // Shared epilogue of the implicit-GEMM kernels (igemm.hip, igemm_pp.hip): accumulators (+bias) -> half -> swizzled LDS
 // tile E[m][n] -> 16-byte coalesced row stores with the residual add and ReLU applied on the way out.
 // Call after a workgroup barrier that retires every read of the staging buffers (the tile reuses them).
-// LDS layout of a kernel that uses it: [0, max(stages, E tile + row tables)) shared by the main loop and the epilogue,
-// then BN floats of bias (ig_lds_bytes).
+// LDS layout of a kernel that uses it: [0, ig_lds_main) shared by the staging buffers of the main loop and, afterwards,
+// the E tile + its two row-offset tables; then IG_BIAS_LDS bytes of bias (ig_bias_to_lds).
 #pragma once
 #include "igemm_common.h"
 
