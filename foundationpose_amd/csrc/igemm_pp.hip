@@ -26,7 +26,7 @@
 
 // DBG != 0 builds timing-only variants that isolate one resource (results are wrong by construction; FP_IGEMM_DBG):
 //   1 every tile stages the A rows of tile 0 (operand stream served by L2), 2 no LDS-DMA in the main loop,
-//   9 no epilogue.  Measured at the bench shapes (256->256 / 512->512 conv, TFLOP/s): normal 948 / 992, (1) 1010 / 991,
+//   3 operands addressed as if the activations were channel-blocked and the weights [k-step][N][32], 9 no epilogue.  Measured at the bench shapes (256->256 / 512->512 conv, TFLOP/s): normal 948 / 992, (1) 1010 / 991,
 //   (2) 1272 / 1395, (9) 1185 / 1103 -- see DESIGN.md 3.2.
 template <int BM, int BN, int TM, int DBG>
 __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
@@ -70,12 +70,14 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
     int m = (DBG == 1 ? 0 : m0) + row;
     m = m < p.M ? m : p.M - 1;
     aoff32[j] = (unsigned)((ig_row_off(p.in, m) + c * 8) * 2);
+    if (DBG == 3) aoff32[j] = (unsigned)(m * 128 + (lane % CPK) * 16);   // timing only: channel-blocked image, pixels 128 B apart
   }
 #pragma unroll
   for (int j = 0; j < WI; ++j) {
     const int row = wid * (WI * RPI) + j * RPI + lane / CPK;
     const int c = (lane % CPK) ^ swz(row);
     woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
+    if (DBG == 3) woff32[j] = (unsigned)((n0 + row) * 64 + (lane % CPK) * 16);   // timing only: [k-step][N][32] weight image
   }
   const int nk = p.taps * (p.Cin / BK);
   int st_ci0 = 0, st_kx = 0, st_ky = 0, st_k = 0;
@@ -84,8 +86,12 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Wt), 0, 0x7FFFFFFF, 0x00020000);
 
   auto stage = [&](int buf) {
-    const int asoff = (((st_ky * inWp + st_kx) * inCs) + st_ci0) * 2;
-    const int wsoff = st_k * (BK * 2);
+    int asoff = (((st_ky * inWp + st_kx) * inCs) + st_ci0) * 2;
+    int wsoff = st_k * (BK * 2);
+    if (DBG == 3) {   // the k-step selects a 64-channel plane (and a half of it) / a contiguous N x 32 weight slab
+      asoff = ((st_k >> 1) % (Cin / 64)) * (p.M * 128) + (st_k & 1) * 64;
+      wsoff = st_k * (p.N * 64);
+    }
     unsigned char* sa = smem + buf * STAGE_BYTES + wid * (AI * 1024);
     unsigned char* sw = smem + buf * STAGE_BYTES + A_BYTES + wid * (WI * 1024);
 #pragma unroll
@@ -387,14 +393,10 @@ int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream) {
       case 1: return ig_pp_launch<256, 256, 4, 1>(p, stream);
       case 2: return ig_pp_launch<256, 256, 4, 2>(p, stream);
       case 3: return ig_pp_launch<256, 256, 4, 3>(p, stream);
-      case 6: return ig_pp_launch<256, 256, 4, 6>(p, stream);
-      case 8: return ig_pp_launch<256, 256, 4, 8>(p, stream);
-      case 9: return ig_pp_launch<256, 256, 4, 9>(p, stream);
-      case 10: return ig_pp_launch<256, 256, 4, 10>(p, stream);
-      case 7: return ig_ppr_launch<256, 256, 4>(p, stream);
-      default: return ig_pp_launch<256, 256, 4, 4>(p, stream);
+      default: return ig_pp_launch<256, 256, 4, 9>(p, stream);
     }
   }
+  if (variant == 3) return ig_ppr_launch<256, 256, 4>(p, stream);
   switch (variant) {
     case 0: return ig_pp_launch<256, 256, 4, 0>(p, stream);
     default: return ig_pp_launch<256, 128, 2, 0>(p, stream);
