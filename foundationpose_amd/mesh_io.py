@@ -1,4 +1,4 @@
-"""Mesh files: Wavefront OBJ (+ MTL + texture image) in and out, numpy + PIL only.
+"""Mesh files: Wavefront OBJ (+ MTL + texture image) and PLY in and out, numpy + PIL only.
 
 The reference loads meshes with trimesh (`run_demo.py:29`, `datareader.py:150`); the hot path touches `.vertices`,
 `.faces`, `.vertex_normals`, `.visual.uv`, `.visual.material.image` / `.visual.vertex_colors` (Utils.py:104-130).
@@ -114,8 +114,112 @@ def save_obj(mesh, path):
             f.write(f"newmtl material_0\nKa 1 1 1\nKd 1 1 1\nKs 0 0 0\nmap_Kd {os.path.basename(stem)}.png\n")
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
+              "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
+              "double": "f8", "float64": "f8"}
+
+
+def load_ply(path):
+    """-> SimpleMesh.  PLY as the BOP model sets ship it: `ascii` or `binary_little_endian`, a vertex element with
+    x y z (+ nx ny nz, + red green blue, + texture_u texture_v) and a face element with one index list (polygons are
+    fan-triangulated); a `comment TextureFile <name>` header line names the texture image."""
+    with open(path, "rb") as f:
+        fmt, elements, texfile = None, [], None
+        line = f.readline().strip()
+        if line != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated PLY header")
+            t = line.decode("ascii", "replace").split()
+            if not t:
+                continue
+            if t[0] == "format":
+                fmt = t[1]
+            elif t[0] == "comment" and len(t) >= 3 and t[1] == "TextureFile":
+                texfile = os.path.join(os.path.dirname(path), t[2])
+            elif t[0] == "element":
+                elements.append((t[1], int(t[2]), []))
+            elif t[0] == "property":
+                elements[-1][2].append(t[1:])
+            elif t[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian"):
+            raise NotImplementedError(f"{path}: PLY format '{fmt}' is not supported")
+        data = {}
+        for name, count, props in elements:
+            scalar = all(pr[0] != "list" for pr in props)
+            if fmt == "ascii":
+                rows = [f.readline().split() for _ in range(count)]
+                if scalar:
+                    arr = np.array(rows, dtype=np.float64).reshape(count, len(props))
+                    data[name] = {pr[-1]: arr[:, i] for i, pr in enumerate(props)}
+                else:
+                    data[name] = {props[0][-1]: [np.array(r[1:1 + int(r[0])], dtype=np.int64) for r in rows]}
+            elif scalar:
+                dt = np.dtype([(pr[-1], "<" + _PLY_TYPES[pr[0]]) for pr in props])
+                arr = np.frombuffer(f.read(dt.itemsize * count), dtype=dt, count=count)
+                data[name] = {n: arr[n].astype(np.float64) for n in arr.dtype.names}
+            else:
+                if len(props) != 1:
+                    raise NotImplementedError(f"{path}: element '{name}' mixes list and scalar properties")
+                ct, it = np.dtype("<" + _PLY_TYPES[props[0][1]]), np.dtype("<" + _PLY_TYPES[props[0][2]])
+                lists = []
+                for _ in range(count):
+                    n = int(np.frombuffer(f.read(ct.itemsize), dtype=ct, count=1)[0])
+                    lists.append(np.frombuffer(f.read(it.itemsize * n), dtype=it, count=n).astype(np.int64))
+                data[name] = {props[0][-1]: lists}
+    v = data["vertex"]
+    vertices = np.stack([v["x"], v["y"], v["z"]], 1)
+    polys = next(iter(data.get("face", {"vertex_indices": []}).values()))
+    faces = np.array([[p[0], p[k], p[k + 1]] for p in polys for k in range(1, len(p) - 1)], dtype=np.int64).reshape(-1, 3)
+    normals = np.stack([v["nx"], v["ny"], v["nz"]], 1) if "nx" in v else None
+    uv = np.stack([v["texture_u"], v["texture_v"]], 1) if "texture_u" in v else None
+    image = None
+    if uv is not None and texfile is not None and os.path.exists(texfile):
+        from PIL import Image
+        image = np.asarray(Image.open(texfile).convert("RGB"))
+    vcol = np.stack([v["red"], v["green"], v["blue"]], 1).astype(np.uint8) if "red" in v and image is None else None
+    return SimpleMesh(vertices, faces, vertex_normals=normals, uv=uv if image is not None else None, texture=image, vertex_colors=vcol)
+
+
+def save_ply(mesh, path, binary=True):
+    """vertex positions + normals (+ colours) and triangles, binary little-endian or ascii"""
+    verts = np.asarray(mesh.vertices, dtype=np.float32)
+    nrm = np.asarray(mesh.vertex_normals, dtype=np.float32)
+    col = getattr(mesh.visual, "vertex_colors", None)
+    col = None if col is None else np.asarray(col)[:, :3].astype(np.uint8)
+    faces = np.asarray(mesh.faces, dtype=np.int32)
+    props = "".join(f"property float {n}\n" for n in ("x", "y", "z", "nx", "ny", "nz"))
+    if col is not None:
+        props += "".join(f"property uchar {n}\n" for n in ("red", "green", "blue"))
+    header = (f"ply\nformat {'binary_little_endian' if binary else 'ascii'} 1.0\nelement vertex {len(verts)}\n{props}"
+              f"element face {len(faces)}\nproperty list uchar int vertex_indices\nend_header\n")
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        if binary:
+            fields = [("p", "<f4", (3,)), ("n", "<f4", (3,))] + ([("c", "u1", (3,))] if col is not None else [])
+            rec = np.zeros(len(verts), dtype=fields)
+            rec["p"], rec["n"] = verts, nrm
+            if col is not None:
+                rec["c"] = col
+            f.write(rec.tobytes())
+            frec = np.zeros(len(faces), dtype=[("k", "u1"), ("i", "<i4", (3,))])
+            frec["k"], frec["i"] = 3, faces
+            f.write(frec.tobytes())
+        else:
+            for i in range(len(verts)):
+                row = list(verts[i]) + list(nrm[i])
+                f.write((" ".join("%.9g" % x for x in row) + ("" if col is None else " %d %d %d" % tuple(col[i])) + "\n").encode())
+            for a, b, c in faces:
+                f.write(f"3 {a} {b} {c}\n".encode())
+
+
 def load_mesh(path):
     ext = os.path.splitext(path)[1].lower()
     if ext == ".obj":
         return load_obj(path)
-    raise NotImplementedError(f"mesh format '{ext}' is not supported (OBJ only)")
+    if ext == ".ply":
+        return load_ply(path)
+    raise NotImplementedError(f"mesh format '{ext}' is not supported (OBJ and PLY only)")

@@ -30,7 +30,7 @@ def compute_auc(errs, max_val=0.1, step=0.001):
         Y[i] = (errs <= x).sum() / len(errs)
         if Y[i] >= 1:
             break
-    return float(np.trapz(Y, X) / max_val)
+    return float(np.trapezoid(Y, X) / max_val)
 
 
 def _jet(v):

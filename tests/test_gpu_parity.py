@@ -677,3 +677,24 @@ def test_get_vis_canvases(scene, dev, gmesh, frame):
     s0, _ = scorer.predict(scene["rgb"], frame["depth_t"], scene["K"], o0, **kw)
     s1, v2 = scorer.predict(scene["rgb"], frame["depth_t"], scene["K"], o0, get_vis=True, **kw)
     assert torch.equal(s0, s1) and v2.dtype == np.uint8 and v2.shape[0] > n * 160 and v2.shape[1] > 4 * 160
+
+
+def test_run_ycb_video_on_a_synthetic_bop_scene(tmp_path, dev):
+    """scripts/run_ycb_video.py: BOP-layout scene + PLY/OBJ models on disk, reset_object + register per keyframe
+    (run_ycb_video.py:43-130), yaml result file, ADD / ADD-S / AUC summary"""
+    import importlib.util
+    import os
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_ycb_video", os.path.join(root, "scripts", "run_ycb_video.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = str(tmp_path / "dbg")
+    summary = mod.main(["--synthetic", "2", "--est_refine_iter", "1", "--debug_dir", d])
+    assert summary["n"] == 2 and 0.0 <= summary["ADD_AUC"] <= 1.0 and 0.0 <= summary["ADDS_AUC"] <= 1.0
+    assert summary["ADDS_mean_m"] <= summary["ADD_mean_m"] + 1e-9      # closest-point distance never exceeds the paired one
+    res = yaml.safe_load(open(os.path.join(d, "ycbv_res.yml")))
+    assert sorted(res[1].keys()) == ["000000", "000001"] and np.asarray(res[1]["000000"][1]).shape == (4, 4)
+    from foundationpose_amd.datareader import YcbVideoReader
+    r = YcbVideoReader(os.path.join(d, "synthetic_bop", "test", "000001"), models_dir=os.path.join(d, "synthetic_bop", "models"))
+    assert r.get_xyz_map(0).shape == (480, 640, 3)

@@ -1,5 +1,6 @@
 """On-disk formats either side of the path: OBJ meshes and demo-format RGB-D sequences."""
 import numpy as np
+import pytest
 
 
 def test_obj_round_trip(tmp_path):
@@ -85,3 +86,51 @@ def test_metrics_and_debug_drawing(scene):
     A = np.random.default_rng(0).random((3, 6, 16, 16)).astype(np.float32)
     c = vis.crop_rows_canvas(A, A)
     assert c.ndim == 3 and c.shape[2] == 3 and c.shape[0] > 3 * 16
+
+
+def _bop_scene(tmp_path, scene):
+    from foundationpose_amd.datareader import write_bop_scene
+    gt2 = scene["gt"].copy()
+    gt2[:3, 3] += [0.3, 0.0, 0.1]
+    m2 = np.zeros_like(scene["mask"]); m2[10:40, 500:560] = 1
+    inst = [[(5, scene["gt"], scene["mask"]), (5, gt2, m2), (9, gt2, m2)], [(5, scene["gt"], scene["mask"])]]
+    sdir, mdir = str(tmp_path / "ycbv" / "test" / "000048"), str(tmp_path / "ycbv" / "models")
+    write_bop_scene(sdir, scene["K"], [scene["rgb"]] * 2, [scene["depth"]] * 2, inst, models_dir=mdir, meshes={5: scene["mesh"]})
+    return sdir, mdir, gt2, m2
+
+
+def test_bop_scene_reader_roundtrip(tmp_path, scene):
+    """BOP layout (reference datareader.py:155-365): camera / GT json, per-instance visible masks, mm models"""
+    from foundationpose_amd.datareader import BopBaseReader, YcbVideoReader
+    sdir, mdir, gt2, m2 = _bop_scene(tmp_path, scene)
+    r = BopBaseReader(sdir, zfar=5.0, models_dir=mdir)
+    assert len(r) == 2 and r.get_video_id() == 48 and r.id_strs == ["000000", "000001"]
+    np.testing.assert_allclose(r.get_K(0), scene["K"])
+    assert (r.get_color(0) == scene["rgb"]).all()
+    d = r.get_depth(0)
+    assert d.dtype == np.float64 and np.abs(d - scene["depth"]).max() <= 0.5e-4 + 1e-9      # 0.1 mm depth units
+    assert r.get_instance_ids_in_image(0).tolist() == [5, 5, 9] and r.get_instance_ids_in_image(1).tolist() == [5]
+    assert (r.get_mask(0, 5) == (scene["mask"] > 0)).all() and (r.get_mask(0, 9) == (m2 > 0)).all()
+    assert r.get_mask(1, 9) is None
+    np.testing.assert_allclose(r.get_gt_poses(0, 5), np.stack([scene["gt"], gt2]), atol=1e-9)
+    np.testing.assert_allclose(r.get_gt_pose(0, 5), scene["gt"], atol=1e-9)
+    np.testing.assert_allclose(r.get_gt_pose(0, 5, mask=m2 > 0), gt2, atol=1e-9)        # the instance under the mask
+    y = YcbVideoReader(sdir, models_dir=mdir)
+    assert y.dataset_name == "ycbv" and y.ob_ids == [5] and y.is_keyframe(0)
+    mesh = y.get_gt_mesh(5)
+    np.testing.assert_allclose(np.sort(np.asarray(mesh.vertices), 0), np.sort(np.asarray(scene["mesh"].vertices), 0), atol=1e-6)
+    assert abs(y.get_model_diameter(5) - np.hypot(0.102, 0.140)) < 1e-3      # models_info diameter = largest vertex distance
+    assert y.symmetry_tfs[5].shape == (1, 4, 4)
+    h = BopBaseReader(sdir, resize=0.5, models_dir=mdir)
+    assert h.get_color(0).shape == (240, 320, 3) and h.get_depth(0).shape == (240, 320) and h.get_K(0)[0, 0] == scene["K"][0, 0] * 0.5
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_ply_roundtrip(tmp_path, scene, binary):
+    from foundationpose_amd.mesh_io import load_mesh, save_ply
+    f = str(tmp_path / "m.ply")
+    save_ply(scene["mesh"], f, binary=binary)
+    m = load_mesh(f)
+    np.testing.assert_allclose(m.vertices, np.asarray(scene["mesh"].vertices, dtype=np.float32), atol=1e-7)
+    assert (m.faces == scene["mesh"].faces).all()
+    np.testing.assert_allclose(m.vertex_normals, scene["mesh"].vertex_normals, atol=1e-6)
