@@ -33,6 +33,7 @@ SIGNATURES = {
     "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "fp_layernorm_f16_fwd": (ci, [vp, vp, vp, cf, vp, ci, ci, vp]),
     "fp_colmean_f16_fwd": (ci, [vp, vp, vp, cf, vp, ci, ci, ci, vp]),
+    "fp_attention_f16_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "fp_cluster_poses": (ci, [cf, cf, vp, ci, vp, ci, vp]),
 }
 

@@ -10,6 +10,7 @@ Everything else is PyTorch-ROCm (MIOpen convs, hipBLASLt GEMMs).  precision='fp3
 (predict_pose_refine.py:190, predict_score.py:193).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -199,11 +200,15 @@ class _MHA:
         self.qkv = _Linear(sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"], dtype, use_hip)
         self.out = _Linear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"], dtype, use_hip)
         self.nhead = nhead
+        self.hip = use_hip and dtype == torch.float16 and os.environ.get("FP_ATTENTION", "hip") == "hip"
 
     def context(self, x):
         """softmax(q k^T / sqrt(d)) v with heads merged, before the output projection: (Bn, L, D)"""
         Bn, L, D = x.shape
         hd = D // self.nhead
+        if self.hip and hd == 128:
+            # the in_proj output goes to the MFMA attention kernel as it stands ([q | k | v] rows), heads merged on the way out
+            return ops.attention_f16(self.qkv(x).reshape(Bn, L, 3 * D), self.nhead)
         qkv = self.qkv(x).reshape(Bn, L, 3, self.nhead, hd)
         q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
         # fused attention: the (Bn*4, L, L) probability tensor (161 M elements at N=252, which the reference

@@ -309,6 +309,18 @@ def colmean_f16(x, gamma=None, beta=None, eps=1e-5):
     return out
 
 
+def attention_f16(qkv, n_heads):
+    """qkv (B, S, 3*D) fp16 = in_proj output [q | k | v] -> (B, S, D) fp16 = softmax(q k^T / sqrt(hd)) v, heads merged
+    (fp_attention_f16_fwd; head size D / n_heads must be 128)"""
+    qkv = _dev(qkv, torch.float16, "qkv")
+    B, S, D3 = (int(v) for v in qkv.shape)
+    D = D3 // 3
+    out = torch.empty((B, S, D), dtype=torch.float16, device=qkv.device)
+    st = _lib.lib().fp_attention_f16_fwd(_ptr(qkv), _ptr(out), B, S, int(n_heads), D // int(n_heads), _stream())
+    _lib.check(st, "fp_attention_f16_fwd")
+    return out
+
+
 def cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs):
     """Host op (init-time): returns indices of the kept poses (mycpp.cluster_poses semantics)."""
     P = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 16))
@@ -404,3 +416,5 @@ linear_f16 = _timed("fp_linear_f16_fwd", linear_f16, _work_linear)
 igemm_f16 = _timed("fp_igemm_f16_fwd", igemm_f16, _work_igemm)
 layernorm_f16 = _timed("fp_layernorm_f16_fwd", layernorm_f16, lambda x, *a, **k: (4.0 * x.numel(), 0.0))
 colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16, lambda x, *a, **k: (2.0 * x.numel(), 0.0))
+attention_f16 = _timed("fp_attention_f16_fwd", attention_f16,
+                       lambda qkv, n_heads: (2.0 * qkv.numel() * 4.0 / 3.0, 4.0 * qkv.shape[0] * qkv.shape[1] ** 2 * (qkv.shape[2] // 3)))

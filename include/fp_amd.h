@@ -161,6 +161,15 @@ int fp_layernorm_f16_fwd(const void* x /*dev*/, const float* gamma /*dev D*/, co
 int fp_colmean_f16_fwd(const void* x /*dev*/, const float* gamma /*dev D|NULL*/, const float* beta /*dev D|NULL*/,
                        float eps, float* out /*dev*/, int groups, int rows_per_group, int D, void* stream);
 
+/* The attention core of nn.MultiheadAttention(512, 4) as the networks call it (query = key = value, no mask, eval):
+ * refine_network.py:56-70 (nn.TransformerEncoderLayer self-attention over the 400 tokens of a hypothesis),
+ * score_network.py:52-53 (token attention) and :84-88 (attention across the hypotheses), i.e. what
+ * torch.nn.functional.multi_head_attention_forward does between in_proj and out_proj:
+ *   out[b, t, h*hd:(h+1)*hd] = softmax_t'(q[b,t,h,:] . k[b,t',h,:] / sqrt(hd)) v[b,t',h,:]
+ * qkv (B*S, 3*H*hd) fp16 = the in_proj output [q | k | v]; out (B*S, H*hd) fp16 = the out_proj input.  hd must be 128.
+ * fp32 scores / softmax / accumulation; the (B*H, S, S) probability tensor is never formed. */
+int fp_attention_f16_fwd(const void* qkv /*dev*/, void* out /*dev*/, int B, int S, int H, int head_dim, void* stream);
+
 /* mycpp/src/app/pybind_api.cpp:24-68 cluster_poses (host, init-time). Returns #kept, indices in keep_idx. */
 int fp_cluster_poses(float angle_diff_deg, float dist_diff, const float* poses /*host N,16*/, int N,
                      const float* symmetry_tfs /*host S,16*/, int S, int* keep_idx /*host N*/);

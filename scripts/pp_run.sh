@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-for d in 0 3; do
-echo "== dbg $d"
-FP_IGEMM_DBG=$d FP_IGEMM_TILE=pp256x256 FP_LAYERS_ONLY=1 timeout 200 python scripts/bench_igemm.py 2>&1 | grep "256->256 40 res=0\|512->512 20 res=0\|igemm linear"
-done
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "attention_kernel" 2>&1 | tail -6
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "fp16_plans or graph or scorer" 2>&1 | tail -3
+timeout 200 python scripts/bench_igemm.py 2>&1 | grep "HipEnc\|RefinePlan\|attention\|   fp_"
+FP_ATTENTION=torch timeout 200 python scripts/bench_igemm.py 2>&1 | grep "RefinePlan"
