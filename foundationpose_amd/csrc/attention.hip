@@ -4,9 +4,9 @@
 // MFMA kernel: the (B*H, S, S) probability tensor (161 M elements at N=252) never exists.
 //
 // Input is the in_proj output as it stands: rows of [q(H*128) | k(H*128) | v(H*128)]; output rows of H*128 (heads merged),
-// the operand of out_proj.  One workgroup = 4 waves = 4 query tiles of 32 rows of one (sequence, head); K and V of that
-// head stream through LDS in blocks of 64 keys (double buffered, the next block is in flight in registers while the
-// current one is multiplied).
+// the operand of out_proj.  One workgroup = 8 waves = 8 query tiles of 32 rows of one (sequence, head); K and V of that
+// head stream through LDS in blocks of 64 keys (double buffered; while a block is multiplied the next K block is in
+// flight as LDS-DMA and the next V block in registers).
 //
 // MFMA bookkeeping (v_mfma_f32_32x32x16_f16; A lane l = A[l&31][8(l>>5)+i], B lane l = B[8(l>>5)+i][l&31],
 // D lane l reg r = D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]):
@@ -33,25 +33,32 @@ typedef unsigned uint4_ __attribute__((ext_vector_type(4)));
 constexpr int AT_D = 128;            // head size
 constexpr int AT_KB = 64;            // keys per LDS block
 constexpr int AT_K_BYTES = AT_KB * AT_D * 2;      // 16 KiB, [key][d], 16-byte chunks XORed with key & 15
-constexpr int AT_V_BYTES = AT_D * AT_KB * 2;      // 16 KiB, [d][key position], key position = key ^ vswz(d)
+constexpr int AT_VROW = 136;                      // bytes per d row of the V^T image: 64 keys + 8 bytes of padding
+constexpr int AT_V_BYTES = AT_D * AT_VROW;        // 17 KiB, [d][key position], key position = key ^ vswz(d)
 constexpr int AT_BUF = AT_K_BYTES + AT_V_BYTES;
-constexpr int AT_LDS = 2 * AT_BUF;                // 64 KiB: two workgroups per CU
+constexpr int AT_LDS = 2 * AT_BUF;                // 66 KiB: two workgroups per CU
 
-__device__ __forceinline__ int vswz(int d) { return (4 * ((d >> 3) ^ (2 * (d & 7)))) & 60; }
+// swizzle of the key position inside a V^T row: bits 3:2 only, so that the k-step (bits 5:4) stays an immediate offset of
+// the fragment reads; with the 136-byte rows both the 8-byte fragment reads and the 16-bit transposing scatter are 2-way
+__device__ __forceinline__ int vswz(int d) { return 4 * ((d >> 3) & 3); }
 
-__global__ __launch_bounds__(256, 2) void k_attention_f16(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
+constexpr int AT_WAVES = 8;                       // query tiles per workgroup: K / V of a head are staged (and V transposed) per
+                                                  // workgroup, so fewer, larger workgroups halve the LDS-write-bound scatter
+constexpr int AT_THREADS = AT_WAVES * 64;
+
+__global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
                                                           int S, int H, float c /* log2(e)/sqrt(d) */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 31, hi = lane >> 5;
-  const int nqg = (S + 127) >> 7;                  // query groups of 128 rows per (sequence, head)
+  const int nqg = (S + 32 * AT_WAVES - 1) / (32 * AT_WAVES);   // query groups of 256 rows per (sequence, head)
   const int qg = blockIdx.x % nqg, bh = blockIdx.x / nqg;
   const int h = bh % H, b = bh / H;
   const int ld = 3 * H * AT_D, ldo = H * AT_D;
   const _Float16* qp = qkv + (size_t)b * S * ld + h * AT_D;
   const _Float16* kp = qp + H * AT_D;
   const _Float16* vp = kp + H * AT_D;
-  const int q0 = qg * 128 + wid * 32;              // first query row of this wave
+  const int q0 = (qg * AT_WAVES + wid) * 32;       // first query row of this wave
   const bool wave_active = q0 < S;                 // idle waves still help staging and keep the barriers matched
 
   // ---- Q fragments (B operand): row q0 + lq, d = 16 kk + 8 hi + 0..7
@@ -64,33 +71,64 @@ __global__ __launch_bounds__(256, 2) void k_attention_f16(const _Float16* __rest
     for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const half8*>(src + 16 * kk);
   }
 
-  // ---- staging: thread t owns chunks c = t + 256 i (i < 4) of a block: key = c / 16, 16-byte chunk dc = c % 16
-  uint4_ rk[4], rv[4];
-  auto gload = [&](int blk) {
+  // ---- staging.  K: LDS-DMA (buffer_load ... lds), 1 KiB = 4 keys per wave-instruction, 2 pieces per wave and block;
+  // the destination is lane-linear, so the XOR swizzle is applied to the SOURCE chunk: LDS chunk position (lane & 15)
+  // of key row k holds d-chunk (lane & 15) ^ (k & 15).  V: through registers (it has to be transposed), thread t owns
+  // chunks c = t + 512 i (i < 2): key = c % 8 + 8 (c / 128), d-chunk = (c / 8) % 16 (8 lanes = 8 consecutive keys).
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kp), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(vp), 0, 0x7FFFFFFF, 0x00020000);
+  constexpr int KPW = 16 / AT_WAVES;               // K pieces per wave and block
+  constexpr int VCH = 1024 / AT_THREADS;           // 16-byte V chunks per thread and block
+  // per-lane byte offsets inside a block, computed once; the block adds a scalar (blk * 64 rows).  Only a block that
+  // reaches past the end of the sequence recomputes them with the row clamped (rows past the end are masked below,
+  // any finite data will do).
+  int koff[KPW], kkey[KPW], voff[VCH], vkey[VCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int cidx = tid + 256 * i;
-      int key = blk * AT_KB + (cidx >> 4);
-      key = key < S ? key : S - 1;                 // rows past the end are masked below; any finite data will do
-      const size_t off = (size_t)key * ld + (cidx & 15) * 8;
-      rk[i] = *reinterpret_cast<const uint4_*>(kp + off);
-      rv[i] = *reinterpret_cast<const uint4_*>(vp + off);
+  for (int i = 0; i < KPW; ++i) {
+    const int piece = wid * KPW + i;
+    kkey[i] = piece * 4 + (lane >> 4);
+    koff[i] = kkey[i] * (ld * 2) + (((lane & 15) ^ (kkey[i] & 15)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < VCH; ++i) {
+    const int cidx = tid + AT_THREADS * i;
+    vkey[i] = (cidx & 7) + 8 * (cidx >> 7);
+    voff[i] = vkey[i] * (ld * 2) + ((cidx >> 3) & 15) * 16;
+  }
+  uint4_ rv[VCH];
+  auto stage_next = [&](int blk, int buf) {        // K of block blk: LDS-DMA into buffer buf; V of block blk: into registers
+    const int soff = blk * AT_KB * (ld * 2);
+    if ((blk + 1) * AT_KB <= S) {
+#pragma unroll
+      for (int i = 0; i < KPW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
+                                                 16, koff[i], soff, 0, 0);
+#pragma unroll
+      for (int i = 0; i < VCH; ++i) rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i], soff, 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const int back = max(blk * AT_KB + kkey[i] - (S - 1), 0) * (ld * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
+                                                 16, koff[i] - back, soff, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < VCH; ++i) {
+        const int back = max(blk * AT_KB + vkey[i] - (S - 1), 0) * (ld * 2);
+        rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i] - back, soff, 0));
+      }
     }
   };
-  auto lstore = [&](int buf) {
-    unsigned char* kb = smem + buf * AT_BUF;
-    unsigned char* vb = kb + AT_K_BYTES;
+  auto vstore = [&](int buf) {
+    unsigned char* vb = smem + buf * AT_BUF + AT_K_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int cidx = tid + 256 * i;
-      const int key = cidx >> 4, dc = cidx & 15;
-      *reinterpret_cast<uint4_*>(kb + key * 256 + ((dc ^ (key & 15)) << 4)) = rk[i];
+    for (int i = 0; i < VCH; ++i) {
+      const int cidx = tid + AT_THREADS * i;
+      const int key = (cidx & 7) + 8 * (cidx >> 7), dc = (cidx >> 3) & 15;
       const half8 v = __builtin_bit_cast(half8, rv[i]);
+      unsigned char* dst = vb + (8 * dc) * AT_VROW + ((key ^ vswz(8 * dc)) << 1);   // vswz is constant over the 8 d of a chunk
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int d = 8 * dc + e;
-        *reinterpret_cast<_Float16*>(vb + d * 128 + ((key ^ vswz(d)) << 1)) = v[e];
-      }
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<_Float16*>(dst + e * AT_VROW) = v[e];
     }
   };
 
@@ -102,85 +140,121 @@ __global__ __launch_bounds__(256, 2) void k_attention_f16(const _Float16* __rest
   float m = -1e30f, l = 0.f;                       // running row max (raw scores) and row sum, per query = per lane pair
 
   const int nblk = (S + AT_KB - 1) / AT_KB;
-  gload(0);
-  lstore(0);
+  stage_next(0, 0);
+  vstore(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int blk = 0; blk < nblk; ++blk) {
     const int cur = blk & 1;
-    if (blk + 1 < nblk) gload(blk + 1);            // in flight while this block is multiplied
+    if (blk + 1 < nblk) stage_next(blk + 1, cur ^ 1);   // in flight while this block is multiplied
     const unsigned char* kb = smem + cur * AT_BUF;
     const unsigned char* vb = kb + AT_K_BYTES;
     if (wave_active) {
+      const int key0 = blk * AT_KB;
+      // ---- S^T tiles = K (2 x 32 keys) x Q^T: two independent accumulator chains
+      float16_ s0, s1;
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
-        const int key0 = blk * AT_KB + 32 * sb;
-        if (key0 >= S) break;                      // wave-uniform
-        // ---- S^T tile = K (32 keys) x Q^T
-        float16_ s;
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      const unsigned char* krp = kb + lq * 256;    // rows lq and 32 + lq share (row & 15)
+      half8 kf[2][2];
+      auto kread = [&](int kk, int slot) {
+        const int pos = ((2 * kk + hi) ^ (lq & 15)) << 4;
+        kf[slot][0] = *reinterpret_cast<const half8*>(krp + pos);
+        kf[slot][1] = *reinterpret_cast<const half8*>(krp + 32 * 256 + pos);
+      };
+      kread(0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const int krow = 32 * sb + lq;
-        const unsigned char* krp = kb + krow * 256;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const half8 kf = *reinterpret_cast<const half8*>(krp + (((2 * kk + hi) ^ (krow & 15)) << 4));
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s, 0, 0, 0);
-        }
-        if (key0 + 32 > S) {                       // keys past the end of the sequence
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= S) s[r] = -1e30f;
-        }
-        // ---- online softmax (base 2, scores scaled by c inside the exponent)
-        float mx = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx);
-        if (__any(mn > m)) {                       // rescale what has been accumulated under the old maximum
-          const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-          l *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-          m = mn;
-        }
-        const float mc = m * c;
-        float rs = 0.f;
-        half8 pf[2];
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk < 7) kread(kk + 1, (kk + 1) & 1);   // the next fragments are on their way while these are multiplied
+        __builtin_amdgcn_sched_barrier(0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk & 1][0], qf[kk], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk & 1][1], qf[kk], s1, 0, 0, 0);
+      }
+      if (key0 + AT_KB > S) {                      // keys past the end of the sequence (last block only)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
-          rs += p;
-          pf[r >> 3][r & 7] = (_Float16)p;
+          const int k = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (k >= S) s0[r] = -1e30f;
+          if (k + 32 >= S) s1[r] = -1e30f;
         }
-        rs += __shfl_xor(rs, 32);
-        l += rs;
-        // ---- O^T += V^T P^T over the 32 keys (two k-steps of 16 permuted keys)
+      }
+      // ---- online softmax over the 64 keys (base 2, scores scaled by c inside the exponent)
+      float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mn = fmaxf(m, mx);
+      if (__any(mn > m)) {                         // rescale what has been accumulated under the old maximum
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        m = mn;
+      }
+      const float mc = m * c;
+      float rs = 0.f;
+      half8 pf[4];                                 // P fragments of the four k-steps (16 permuted keys each)
+      {
+        typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+        unsigned pw[4][4];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc)), a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
+          const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc)), b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
+          rs += (a0 + a1) + (b0 + b1);
+          const half2_ ha = {(_Float16)a0, (_Float16)a1}, hb = {(_Float16)b0, (_Float16)b1};   // one v_cvt_pk_f16_f32 each
+          pw[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(unsigned, ha);
+          pw[2 + (r >> 3)][(r & 7) >> 1] = __builtin_bit_cast(unsigned, hb);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint4_ w = {pw[t][0], pw[t][1], pw[t][2], pw[t][3]};
+          pf[t] = __builtin_bit_cast(half8, w);
+        }
+      }
+      rs += __shfl_xor(rs, 32);
+      l += rs;
+      // ---- O^T += V^T P^T: k-step outer, d tile inner (four independent accumulators in rotation); the fragments of
+      // the next k-step are requested before the MFMAs of this one
+      const unsigned char* vr0[4];
+      const unsigned char* vr1[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = 32 * dt + lq;
+        vr0[dt] = vb + d * AT_VROW + (((4 * hi) ^ vswz(d)) << 1);
+        vr1[dt] = vb + d * AT_VROW + (((8 + 4 * hi) ^ vswz(d)) << 1);
+      }
+      half4 va[2][4], vc[2][4];
+      auto vread = [&](int ks, int slot) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const int d = 32 * dt + lq;
-          const unsigned char* vrp = vb + d * 128;
-          const int sw = vswz(d);
+          va[slot][dt] = *reinterpret_cast<const half4*>(vr0[dt] + 32 * ks);
+          vc[slot][dt] = *reinterpret_cast<const half4*>(vr1[dt] + 32 * ks);
+        }
+      };
+      vread(0, 0);
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int kp0 = 32 * sb + 16 * ks + 4 * hi;
-            const half4 lo = *reinterpret_cast<const half4*>(vrp + ((kp0 ^ sw) << 1));
-            const half4 hi4 = *reinterpret_cast<const half4*>(vrp + (((kp0 + 8) ^ sw) << 1));
-            const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[dt], 0, 0, 0);
-          }
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) vread(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const half4 lo = va[ks & 1][dt], hi4 = vc[ks & 1][dt];
+          const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[dt], 0, 0, 0);
         }
       }
     }
-    if (blk + 1 < nblk) lstore(cur ^ 1);
+    if (blk + 1 < nblk) vstore(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K pieces of the next block have landed
     __syncthreads();
   }
 
   // ---- normalise, transpose through a wave-private LDS tile [32 queries][128 d] (16-byte chunks XORed with q & 15),
   // store whole 256-byte rows
-  unsigned char* tile = smem + wid * (32 * 256);   // 4 x 8 KiB inside buffer 0 + 1 (everyone is past the last barrier)
+  unsigned char* tile = smem + wid * (32 * 256);   // 8 x 8 KiB inside the two buffers (everyone is past the last barrier)
   if (wave_active) {
     const float inv = 1.0f / l;
 #pragma unroll
@@ -216,7 +290,7 @@ extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, in
   FP_REQUIRE(qkv && out, "fp_attention_f16_fwd: NULL tensor");
   FP_REQUIRE(head_dim == AT_D, "fp_attention_f16_fwd: head_dim=%d (only 128 is built)", head_dim);
   FP_REQUIRE(H > 0 && ((((size_t)qkv | (size_t)out) & 15) == 0), "fp_attention_f16_fwd: bad head count / unaligned tensors");
-  const long long wgs = (long long)B * H * ((S + 127) / 128);
+  const long long wgs = (long long)B * H * ((S + 32 * AT_WAVES - 1) / (32 * AT_WAVES));
   FP_REQUIRE(wgs < (1ll << 31), "fp_attention_f16_fwd: too many workgroups");
   static bool attr_set = false;
   if (!attr_set) {
@@ -224,7 +298,7 @@ extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, in
     attr_set = true;
   }
   const float c = 1.4426950408889634f / sqrtf((float)head_dim);
-  hipLaunchKernelGGL(k_attention_f16, dim3((unsigned)wgs), dim3(256), AT_LDS, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_attention_f16, dim3((unsigned)wgs), dim3(AT_THREADS), AT_LDS, (hipStream_t)stream,
                      (const _Float16*)qkv, (_Float16*)out, S, H, c);
   FP_CHECK_LAUNCH("fp_attention_f16_fwd");
   return FP_OK;
