@@ -28,7 +28,7 @@ SCORE_GFLOP_CROSS_252 = 0.659
 # roofline that bounds each hand-written kernel (DESIGN.md "Kernels")
 KERNEL_BOUND = {"fp_render_crops": "hbm", "fp_warp_crops": "hbm", "fp_conv7x7s2_bn_relu_fwd": "hbm",
                 "fp_linear_f16_fwd": "mfma", "fp_igemm_f16_fwd": "mfma", "fp_layernorm_f16_fwd": "hbm",
-                "fp_colmean_f16_fwd": "hbm"}
+                "fp_colmean_f16_fwd": "hbm", "fp_attention_f16_fwd": "mfma"}
 
 
 def measured_traffic(kernel):

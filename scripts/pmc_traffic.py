@@ -9,7 +9,7 @@ import collections, csv, json, os, sys
 
 ENTRY = {"k_vertex": "fp_render_crops", "k_bin": "fp_render_crops", "k_raster": "fp_render_crops", "k_warp": "fp_warp_crops", "k_conv7x7s2": "fp_conv7x7s2_bn_relu_fwd",
          "k_igemm_f16": "fp_igemm_f16_fwd", "k_igemm_pp": "fp_igemm_f16_fwd", "k_linear_f16": "fp_linear_f16_fwd", "k_layernorm512": "fp_layernorm_f16_fwd",
-         "k_colmean512": "fp_colmean_f16_fwd"}
+         "k_colmean512": "fp_colmean_f16_fwd", "k_attention_f16": "fp_attention_f16_fwd"}
 
 
 def load(path, counter):

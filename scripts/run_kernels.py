@@ -36,6 +36,7 @@ for _ in range(reps):
     y = ops.conv7x7s2_bn_relu(AB, w1, sc1, sh1, channels_last=True)
     q = ops.linear_f16(x, wq, bq)
     ops.igemm_f16(xi, G.image(40, 40, 1, 256, offset=0), wi, None, yi, G.image(40, 40, 1, 256), N * 1600, 256, 256, 9, relu=True)
+    ops.attention_f16(q.reshape(N, 400, 1536), 4)
     ops.layernorm_f16(xt, lnw, lnb)
     ops.colmean_f16(xt, lnw, lnb)
 torch.cuda.synchronize()
