@@ -1,13 +1,17 @@
-"""Inference plans for RefineNet / ScoreNetMultiPair on PyTorch-ROCm.
+"""Inference plans for RefineNet / ScoreNetMultiPair.
 
-A plan is built once from a module's state_dict (reference checkpoints load unchanged): eval-mode BatchNorm is
-folded into the preceding conv, weights are cast to the compute dtype, and the two layers the north-star names are
-routed to hand-written MFMA kernels of libfp_amd.so (fp16 plans only):
-  * patch-embed conv  (7x7 s2, 6->64 + BN + ReLU)  -> fp_conv7x7s2_bn_relu_fwd
-  * QKV in_proj (512->1536) and the other 512-wide projections -> fp_linear_f16_fwd
-Everything else is PyTorch-ROCm (MIOpen convs, hipBLASLt GEMMs).  precision='fp32' is the parity configuration
-(all torch ops, fp32, no autocast); precision='fp16' mirrors the reference's autocast(fp16) deployment
-(predict_pose_refine.py:190, predict_score.py:193).
+A plan is built once from a module's state_dict (reference checkpoints load unchanged): eval-mode BatchNorm is folded
+into the preceding conv and weights are cast to the compute dtype.
+
+precision='fp16' (deployment; mirrors the reference's autocast(fp16), predict_pose_refine.py:190, predict_score.py:193)
+runs the whole network on libfp_amd.so:
+  * patch-embed conv (7x7 s2, 6->64 + BN + ReLU)            -> fp_conv7x7s2_bn_relu_fwd
+  * the 15 3x3 convs and every 512-wide projection          -> fp_igemm_f16_fwd (bias / residual / ReLU fused)
+  * self-attention between in_proj and out_proj             -> fp_attention_f16_fwd
+  * LayerNorm, LayerNorm + token mean                       -> fp_layernorm_f16_fwd, fp_colmean_f16_fwd
+What is left to PyTorch are the tiny N-row tensors after the token mean (head linears on N x 512, the scorer's final
+Linear) and elementwise glue (2.6 % of the GPU time, profiles/README.md).
+precision='fp32' is the parity configuration: all torch ops, fp32, no autocast.
 """
 import math
 import os
