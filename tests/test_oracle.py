@@ -160,3 +160,22 @@ def test_pose_update_against_scipy(scene):
     np.testing.assert_allclose(out6[:, :3, 3], P[:, :3, 3] + np.tanh(tr) * np.array([0.02, 0.02, 0.05]), atol=1e-6)
     Rd = out6[:, :3, :3] @ P[:, :3, :3].transpose(0, 2, 1)
     np.testing.assert_allclose(Rd @ Rd.transpose(0, 2, 1), np.tile(np.eye(3), (8, 1, 1)), atol=1e-5)
+
+
+def test_attention_core_definition_matches_nn_multiheadattention():
+    """fp_attention_f16_fwd is specified (include/fp_amd.h) as what nn.MultiheadAttention(512, 4, batch_first=True) does
+    between in_proj and out_proj when called as att(x, x, x) (refine_network.py:56-70 via nn.TransformerEncoderLayer,
+    score_network.py:52-53, :84-88).  This pins that formula -- the one tests/test_gpu_parity.py checks the kernel
+    against -- to the torch module itself."""
+    import torch
+    torch.manual_seed(0)
+    att = torch.nn.MultiheadAttention(512, 4, batch_first=True).eval()
+    x = torch.randn(3, 37, 512)
+    with torch.no_grad():
+        want, _ = att(x, x, x, need_weights=False)
+        qkv = torch.nn.functional.linear(x, att.in_proj_weight, att.in_proj_bias)          # (B, S, [q | k | v])
+        B, S, H, hd = 3, 37, 4, 128
+        q, k, v = (qkv.reshape(B, S, 3, H, hd)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        ctx = (torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, S, H * hd)
+        got = att.out_proj(ctx)
+    assert (got - want).abs().max().item() < 1e-5
