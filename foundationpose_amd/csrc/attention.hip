@@ -18,8 +18,8 @@
 //     16s + 4(l>>5) + (i&3) + 8(i>>2), which is exactly the order in which a lane already holds its probabilities
 //     (registers 8s..8s+7 of the score tile) -- no cross-lane movement between the two products; V^T is read from LDS
 //     with the same permutation (two 8-byte reads of 4 consecutive keys each).
-//   * V arrives [key][d] and is transposed while it is written to LDS (16-bit scatter, XOR-swizzled so that the
-//     fragment reads are conflict-free and the scatter is 2-way).
+//   * V arrives [key][d] and is transposed on its way into LDS: a 4x4 register transpose inside each lane quad (DPP),
+//     then 8-byte stores of four consecutive keys into a [d][key] image with 136-byte rows (conflict-free both ways).
 #include <hip/hip_fp16.h>
 #include "fp_common.h"
 
@@ -34,13 +34,25 @@ constexpr int AT_D = 128;            // head size
 constexpr int AT_KB = 64;            // keys per LDS block
 constexpr int AT_K_BYTES = AT_KB * AT_D * 2;      // 16 KiB, [key][d], 16-byte chunks XORed with key & 15
 constexpr int AT_VROW = 136;                      // bytes per d row of the V^T image: 64 keys + 8 bytes of padding
-constexpr int AT_V_BYTES = AT_D * AT_VROW;        // 17 KiB, [d][key position], key position = key ^ vswz(d)
+constexpr int AT_V_BYTES = AT_D * AT_VROW;        // 17 KiB, [d][key]: with the padded rows both the 8-byte fragment reads
+                                                  // and the 8-byte transposing stores are conflict-free
 constexpr int AT_BUF = AT_K_BYTES + AT_V_BYTES;
 constexpr int AT_LDS = 2 * AT_BUF;                // 66 KiB: two workgroups per CU
 
-// swizzle of the key position inside a V^T row: bits 3:2 only, so that the k-step (bits 5:4) stays an immediate offset of
-// the fragment reads; with the 136-byte rows both the 8-byte fragment reads and the 16-bit transposing scatter are 2-way
-__device__ __forceinline__ int vswz(int d) { return 4 * ((d >> 3) & 3); }
+// 4x4 transpose of 32-bit values across the four lanes of a quad (lane j row j -> lane j column j), two DPP exchanges
+__device__ __forceinline__ void quad_transpose(unsigned (&r)[4], int j) {
+  const bool o1 = j & 1, o2 = j & 2;
+  {
+    const unsigned a = __builtin_amdgcn_mov_dpp((int)(o1 ? r[0] : r[1]), 0xB1, 0xF, 0xF, true);   // partner lane ^ 1
+    const unsigned b = __builtin_amdgcn_mov_dpp((int)(o1 ? r[2] : r[3]), 0xB1, 0xF, 0xF, true);
+    if (o1) { r[0] = a; r[2] = b; } else { r[1] = a; r[3] = b; }
+  }
+  {
+    const unsigned a = __builtin_amdgcn_mov_dpp((int)(o2 ? r[0] : r[2]), 0x4E, 0xF, 0xF, true);   // partner lane ^ 2
+    const unsigned b = __builtin_amdgcn_mov_dpp((int)(o2 ? r[1] : r[3]), 0x4E, 0xF, 0xF, true);
+    if (o2) { r[0] = a; r[1] = b; } else { r[2] = a; r[3] = b; }
+  }
+}
 
 constexpr int AT_WAVES = 8;                       // query tiles per workgroup: K / V of a head are staged (and V transposed) per
                                                   // workgroup, so fewer, larger workgroups halve the LDS-write-bound scatter
@@ -119,16 +131,23 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
       }
     }
   };
+  // V chunk (one key, 8 d) -> V^T image: the four lanes of a quad hold four consecutive keys of the same d-chunk; after a
+  // 4x4 transpose of their d-pairs lane j owns d = 8 dc + 2j, 2j + 1 for the four keys: two 8-byte stores instead of
+  // eight 16-bit ones (the 16-bit scatter made the kernel LDS-write bound)
   auto vstore = [&](int buf) {
     unsigned char* vb = smem + buf * AT_BUF + AT_K_BYTES;
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
       const int cidx = tid + AT_THREADS * i;
-      const int key = (cidx & 7) + 8 * (cidx >> 7), dc = (cidx >> 3) & 15;
-      const half8 v = __builtin_bit_cast(half8, rv[i]);
-      unsigned char* dst = vb + (8 * dc) * AT_VROW + ((key ^ vswz(8 * dc)) << 1);   // vswz is constant over the 8 d of a chunk
-#pragma unroll
-      for (int e = 0; e < 8; ++e) *reinterpret_cast<_Float16*>(dst + e * AT_VROW) = v[e];
+      const int k0 = 4 * ((cidx >> 2) & 1) + 8 * (cidx >> 7), dc = (cidx >> 3) & 15, j = cidx & 3;
+      unsigned r[4] = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
+      quad_transpose(r, j);                        // r[t] = (d = 8 dc + 2j | d + 1) of key k0 + t
+      unsigned char* dst = vb + (8 * dc + 2 * j) * AT_VROW + k0 * 2;
+      typedef unsigned uint2_ __attribute__((ext_vector_type(2)));
+      const uint2_ lo = {__builtin_amdgcn_perm(r[1], r[0], 0x05040100u), __builtin_amdgcn_perm(r[3], r[2], 0x05040100u)};
+      const uint2_ hi2 = {__builtin_amdgcn_perm(r[1], r[0], 0x07060302u), __builtin_amdgcn_perm(r[3], r[2], 0x07060302u)};
+      *reinterpret_cast<uint2_*>(dst) = lo;
+      *reinterpret_cast<uint2_*>(dst + AT_VROW) = hi2;
     }
   };
 
@@ -223,8 +242,8 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int d = 32 * dt + lq;
-        vr0[dt] = vb + d * AT_VROW + (((4 * hi) ^ vswz(d)) << 1);
-        vr1[dt] = vb + d * AT_VROW + (((8 + 4 * hi) ^ vswz(d)) << 1);
+        vr0[dt] = vb + d * AT_VROW + 8 * hi;
+        vr1[dt] = vb + d * AT_VROW + 16 + 8 * hi;
       }
       half4 va[2][4], vc[2][4];
       auto vread = [&](int ks, int slot) {
