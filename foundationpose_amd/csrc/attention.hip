@@ -5,8 +5,8 @@
 //
 // Input is the in_proj output as it stands: rows of [q(H*128) | k(H*128) | v(H*128)]; output rows of H*128 (heads merged),
 // the operand of out_proj.  One workgroup = 8 waves = 8 query tiles of 32 rows of one (sequence, head); K and V of that
-// head stream through LDS in blocks of 64 keys (double buffered; while a block is multiplied the next K block is in
-// flight as LDS-DMA and the next V block in registers).
+// head stream through LDS in blocks of 64 keys with a prefetch distance of two blocks (K: LDS-DMA into a ring of three
+// buffers; V: two register sets, transposed into one of two LDS images one block ahead).
 //
 // MFMA bookkeeping (v_mfma_f32_32x32x16_f16; A lane l = A[l&31][8(l>>5)+i], B lane l = B[8(l>>5)+i][l&31],
 // D lane l reg r = D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]):
@@ -36,8 +36,9 @@ constexpr int AT_K_BYTES = AT_KB * AT_D * 2;      // 16 KiB, [key][d], 16-byte c
 constexpr int AT_VROW = 136;                      // bytes per d row of the V^T image: 64 keys + 8 bytes of padding
 constexpr int AT_V_BYTES = AT_D * AT_VROW;        // 17 KiB, [d][key]: with the padded rows both the 8-byte fragment reads
                                                   // and the 8-byte transposing stores are conflict-free
-constexpr int AT_BUF = AT_K_BYTES + AT_V_BYTES;
-constexpr int AT_LDS = 2 * AT_BUF;                // 66 KiB: two workgroups per CU
+constexpr int AT_KBUFS = 3;                       // K blocks in LDS: the one being multiplied + two in flight (LDS-DMA)
+constexpr int AT_V_OFF = AT_KBUFS * AT_K_BYTES;   // two V^T images behind them (the second-next V block waits in registers)
+constexpr int AT_LDS = AT_V_OFF + 2 * AT_V_BYTES; // 82 KiB
 
 // 4x4 transpose of 32-bit values across the four lanes of a quad (lane j row j -> lane j column j), two DPP exchanges
 __device__ __forceinline__ void quad_transpose(unsigned (&r)[4], int j) {
@@ -107,35 +108,34 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     vkey[i] = (cidx & 7) + 8 * (cidx >> 7);
     voff[i] = vkey[i] * (ld * 2) + ((cidx >> 3) & 15) * 16;
   }
-  uint4_ rv[VCH];
-  auto stage_next = [&](int blk, int buf) {        // K of block blk: LDS-DMA into buffer buf; V of block blk: into registers
+  // Prefetch distance is TWO blocks (a block is ~1.5 us of work for a wave, a loaded HBM / L2 round trip is more): at the
+  // top of iteration blk the K block blk+2 leaves as LDS-DMA into the third K buffer and the V block blk+2 into the
+  // register set that the previous iteration emptied.  Loads are issued unconditionally with the row clamped to S-1
+  // (rows past the end are masked below; past the last block they land in a buffer nobody reads), so that the
+  // compiler's vmcnt bookkeeping for the register sets stays exact.
+  uint4_ rva[VCH], rvb[VCH];
+  auto kdma = [&](int blk, int kbuf) {
     const int soff = blk * AT_KB * (ld * 2);
-    if ((blk + 1) * AT_KB <= S) {
 #pragma unroll
-      for (int i = 0; i < KPW; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
-                                                 16, koff[i], soff, 0, 0);
+    for (int i = 0; i < KPW; ++i) {
+      const int back = max(blk * AT_KB + kkey[i] - (S - 1), 0) * (ld * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + kbuf * AT_K_BYTES + (wid * KPW + i) * 1024),
+                                               16, koff[i] - back, soff, 0, 0);
+    }
+  };
+  auto vload = [&](int blk, uint4_ (&rv)[VCH]) {
+    const int soff = blk * AT_KB * (ld * 2);
 #pragma unroll
-      for (int i = 0; i < VCH; ++i) rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i], soff, 0));
-    } else {
-#pragma unroll
-      for (int i = 0; i < KPW; ++i) {
-        const int back = max(blk * AT_KB + kkey[i] - (S - 1), 0) * (ld * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
-                                                 16, koff[i] - back, soff, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < VCH; ++i) {
-        const int back = max(blk * AT_KB + vkey[i] - (S - 1), 0) * (ld * 2);
-        rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i] - back, soff, 0));
-      }
+    for (int i = 0; i < VCH; ++i) {
+      const int back = max(blk * AT_KB + vkey[i] - (S - 1), 0) * (ld * 2);
+      rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i] - back, soff, 0));
     }
   };
   // V chunk (one key, 8 d) -> V^T image: the four lanes of a quad hold four consecutive keys of the same d-chunk; after a
   // 4x4 transpose of their d-pairs lane j owns d = 8 dc + 2j, 2j + 1 for the four keys: two 8-byte stores instead of
   // eight 16-bit ones (the 16-bit scatter made the kernel LDS-write bound)
-  auto vstore = [&](int buf) {
-    unsigned char* vb = smem + buf * AT_BUF + AT_K_BYTES;
+  auto vstore = [&](int vbuf, uint4_ (&rv)[VCH]) {
+    unsigned char* vb = smem + AT_V_OFF + vbuf * AT_V_BYTES;
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
       const int cidx = tid + AT_THREADS * i;
@@ -159,15 +159,22 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
   float m = -1e30f, l = 0.f;                       // running row max (raw scores) and row sum, per query = per lane pair
 
   const int nblk = (S + AT_KB - 1) / AT_KB;
-  stage_next(0, 0);
-  vstore(0);
+  kdma(0, 0);
+  vload(0, rva);
+  kdma(1, 1);
+  vload(1, rvb);
+  vstore(0, rva);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int blk = 0; blk < nblk; ++blk) {
+  int kcur = 0;                                    // K buffer of the current block (blk % 3)
+  // one block; (rv_next, rv_free) = register sets holding V of block blk+1 / free for block blk+2
+  auto block = [&](int blk, uint4_ (&rv_next)[VCH], uint4_ (&rv_free)[VCH]) {
     const int cur = blk & 1;
-    if (blk + 1 < nblk) stage_next(blk + 1, cur ^ 1);   // in flight while this block is multiplied
-    const unsigned char* kb = smem + cur * AT_BUF;
-    const unsigned char* vb = kb + AT_K_BYTES;
+    const int knext2 = kcur == 0 ? 2 : kcur - 1;   // (blk + 2) % 3
+    kdma(blk + 2, knext2);
+    vload(blk + 2, rv_free);
+    const unsigned char* kb = smem + kcur * AT_K_BYTES;
+    const unsigned char* vb = smem + AT_V_OFF + cur * AT_V_BYTES;
     if (wave_active) {
       const int key0 = blk * AT_KB;
       // ---- S^T tiles = K (2 x 32 keys) x Q^T: two independent accumulator chains
@@ -266,14 +273,23 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
         }
       }
     }
-    if (blk + 1 < nblk) vstore(cur ^ 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K pieces of the next block have landed
+    vstore(cur ^ 1, rv_next);                      // V of block blk+1 (loaded one iteration ago) -> the other V^T image
+    // K of block blk+1 (2 DMA per wave, issued one iteration ago) must have landed; this iteration's 2 + 2 may fly on
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
+    kcur = kcur == 2 ? 0 : kcur + 1;
+  };
+  static_assert(KPW + VCH == 4, "the counted wait above assumes 2 K pieces + 2 V chunks per wave and block");
+  for (int blk = 0; blk < nblk; blk += 2) {
+    block(blk, rvb, rva);
+    if (blk + 1 < nblk) block(blk + 1, rva, rvb);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stray prefetches past the last block must not land in the output tiles
+  __syncthreads();
 
   // ---- normalise, transpose through a wave-private LDS tile [32 queries][128 d] (16-byte chunks XORed with q & 15),
   // store whole 256-byte rows
-  unsigned char* tile = smem + wid * (32 * 256);   // 8 x 8 KiB inside the two buffers (everyone is past the last barrier)
+  unsigned char* tile = smem + wid * (32 * 256);   // 8 x 8 KiB laid over the K / V buffers (everyone is past the last barrier)
   if (wave_active) {
     const float inv = 1.0f / l;
 #pragma unroll
