@@ -5,8 +5,8 @@
 //
 // Input is the in_proj output as it stands: rows of [q(H*128) | k(H*128) | v(H*128)]; output rows of H*128 (heads merged),
 // the operand of out_proj.  One workgroup = 8 waves = 8 query tiles of 32 rows of one (sequence, head); K and V of that
-// head stream through LDS in blocks of 64 keys with a prefetch distance of two blocks (K: LDS-DMA into a ring of three
-// buffers; V: two register sets, transposed into one of two LDS images one block ahead).
+// head stream through LDS in blocks of 64 keys (double buffered; while a block is multiplied the next K block is in
+// flight as LDS-DMA and the next V block in registers).
 //
 // MFMA bookkeeping (v_mfma_f32_32x32x16_f16; A lane l = A[l&31][8(l>>5)+i], B lane l = B[8(l>>5)+i][l&31],
 // D lane l reg r = D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]):
@@ -18,8 +18,8 @@
 //     16s + 4(l>>5) + (i&3) + 8(i>>2), which is exactly the order in which a lane already holds its probabilities
 //     (registers 8s..8s+7 of the score tile) -- no cross-lane movement between the two products; V^T is read from LDS
 //     with the same permutation (two 8-byte reads of 4 consecutive keys each).
-//   * V arrives [key][d] and is transposed on its way into LDS: a 4x4 register transpose inside each lane quad (DPP),
-//     then 8-byte stores of four consecutive keys into a [d][key] image with 136-byte rows (conflict-free both ways).
+//   * V arrives [key][d] and is transposed while it is written to LDS (16-bit scatter, XOR-swizzled so that the
+//     fragment reads are conflict-free and the scatter is 2-way).
 #include <hip/hip_fp16.h>
 #include "fp_common.h"
 
@@ -34,26 +34,13 @@ constexpr int AT_D = 128;            // head size
 constexpr int AT_KB = 64;            // keys per LDS block
 constexpr int AT_K_BYTES = AT_KB * AT_D * 2;      // 16 KiB, [key][d], 16-byte chunks XORed with key & 15
 constexpr int AT_VROW = 136;                      // bytes per d row of the V^T image: 64 keys + 8 bytes of padding
-constexpr int AT_V_BYTES = AT_D * AT_VROW;        // 17 KiB, [d][key]: with the padded rows both the 8-byte fragment reads
-                                                  // and the 8-byte transposing stores are conflict-free
-constexpr int AT_KBUFS = 3;                       // K blocks in LDS: the one being multiplied + two in flight (LDS-DMA)
-constexpr int AT_V_OFF = AT_KBUFS * AT_K_BYTES;   // two V^T images behind them (the second-next V block waits in registers)
-constexpr int AT_LDS = AT_V_OFF + 2 * AT_V_BYTES; // 82 KiB
+constexpr int AT_V_BYTES = AT_D * AT_VROW;        // 17 KiB, [d][key position], key position = key ^ vswz(d)
+constexpr int AT_BUF = AT_K_BYTES + AT_V_BYTES;
+constexpr int AT_LDS = 2 * AT_BUF;                // 66 KiB: two workgroups per CU
 
-// 4x4 transpose of 32-bit values across the four lanes of a quad (lane j row j -> lane j column j), two DPP exchanges
-__device__ __forceinline__ void quad_transpose(unsigned (&r)[4], int j) {
-  const bool o1 = j & 1, o2 = j & 2;
-  {
-    const unsigned a = __builtin_amdgcn_mov_dpp((int)(o1 ? r[0] : r[1]), 0xB1, 0xF, 0xF, true);   // partner lane ^ 1
-    const unsigned b = __builtin_amdgcn_mov_dpp((int)(o1 ? r[2] : r[3]), 0xB1, 0xF, 0xF, true);
-    if (o1) { r[0] = a; r[2] = b; } else { r[1] = a; r[3] = b; }
-  }
-  {
-    const unsigned a = __builtin_amdgcn_mov_dpp((int)(o2 ? r[0] : r[2]), 0x4E, 0xF, 0xF, true);   // partner lane ^ 2
-    const unsigned b = __builtin_amdgcn_mov_dpp((int)(o2 ? r[1] : r[3]), 0x4E, 0xF, 0xF, true);
-    if (o2) { r[0] = a; r[1] = b; } else { r[2] = a; r[3] = b; }
-  }
-}
+// swizzle of the key position inside a V^T row: bits 3:2 only, so that the k-step (bits 5:4) stays an immediate offset of
+// the fragment reads; with the 136-byte rows both the 8-byte fragment reads and the 16-bit transposing scatter are 2-way
+__device__ __forceinline__ int vswz(int d) { return 4 * ((d >> 3) & 3); }
 
 constexpr int AT_WAVES = 8;                       // query tiles per workgroup: K / V of a head are staged (and V transposed) per
                                                   // workgroup, so fewer, larger workgroups halve the LDS-write-bound scatter
@@ -108,46 +95,40 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     vkey[i] = (cidx & 7) + 8 * (cidx >> 7);
     voff[i] = vkey[i] * (ld * 2) + ((cidx >> 3) & 15) * 16;
   }
-  // Prefetch distance is TWO blocks (a block is ~1.5 us of work for a wave, a loaded HBM / L2 round trip is more): at the
-  // top of iteration blk the K block blk+2 leaves as LDS-DMA into the third K buffer and the V block blk+2 into the
-  // register set that the previous iteration emptied.  Loads are issued unconditionally with the row clamped to S-1
-  // (rows past the end are masked below; past the last block they land in a buffer nobody reads), so that the
-  // compiler's vmcnt bookkeeping for the register sets stays exact.
-  uint4_ rva[VCH], rvb[VCH];
-  auto kdma = [&](int blk, int kbuf) {
+  uint4_ rv[VCH];
+  auto stage_next = [&](int blk, int buf) {        // K of block blk: LDS-DMA into buffer buf; V of block blk: into registers
     const int soff = blk * AT_KB * (ld * 2);
+    if ((blk + 1) * AT_KB <= S) {
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-      const int back = max(blk * AT_KB + kkey[i] - (S - 1), 0) * (ld * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + kbuf * AT_K_BYTES + (wid * KPW + i) * 1024),
-                                               16, koff[i] - back, soff, 0, 0);
+      for (int i = 0; i < KPW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
+                                                 16, koff[i], soff, 0, 0);
+#pragma unroll
+      for (int i = 0; i < VCH; ++i) rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i], soff, 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const int back = max(blk * AT_KB + kkey[i] - (S - 1), 0) * (ld * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
+                                                 16, koff[i] - back, soff, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < VCH; ++i) {
+        const int back = max(blk * AT_KB + vkey[i] - (S - 1), 0) * (ld * 2);
+        rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i] - back, soff, 0));
+      }
     }
   };
-  auto vload = [&](int blk, uint4_ (&rv)[VCH]) {
-    const int soff = blk * AT_KB * (ld * 2);
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-      const int back = max(blk * AT_KB + vkey[i] - (S - 1), 0) * (ld * 2);
-      rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i] - back, soff, 0));
-    }
-  };
-  // V chunk (one key, 8 d) -> V^T image: the four lanes of a quad hold four consecutive keys of the same d-chunk; after a
-  // 4x4 transpose of their d-pairs lane j owns d = 8 dc + 2j, 2j + 1 for the four keys: two 8-byte stores instead of
-  // eight 16-bit ones (the 16-bit scatter made the kernel LDS-write bound)
-  auto vstore = [&](int vbuf, uint4_ (&rv)[VCH]) {
-    unsigned char* vb = smem + AT_V_OFF + vbuf * AT_V_BYTES;
+  auto vstore = [&](int buf) {
+    unsigned char* vb = smem + buf * AT_BUF + AT_K_BYTES;
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
       const int cidx = tid + AT_THREADS * i;
-      const int k0 = 4 * ((cidx >> 2) & 1) + 8 * (cidx >> 7), dc = (cidx >> 3) & 15, j = cidx & 3;
-      unsigned r[4] = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]};
-      quad_transpose(r, j);                        // r[t] = (d = 8 dc + 2j | d + 1) of key k0 + t
-      unsigned char* dst = vb + (8 * dc + 2 * j) * AT_VROW + k0 * 2;
-      typedef unsigned uint2_ __attribute__((ext_vector_type(2)));
-      const uint2_ lo = {__builtin_amdgcn_perm(r[1], r[0], 0x05040100u), __builtin_amdgcn_perm(r[3], r[2], 0x05040100u)};
-      const uint2_ hi2 = {__builtin_amdgcn_perm(r[1], r[0], 0x07060302u), __builtin_amdgcn_perm(r[3], r[2], 0x07060302u)};
-      *reinterpret_cast<uint2_*>(dst) = lo;
-      *reinterpret_cast<uint2_*>(dst + AT_VROW) = hi2;
+      const int key = (cidx & 7) + 8 * (cidx >> 7), dc = (cidx >> 3) & 15;
+      const half8 v = __builtin_bit_cast(half8, rv[i]);
+      unsigned char* dst = vb + (8 * dc) * AT_VROW + ((key ^ vswz(8 * dc)) << 1);   // vswz is constant over the 8 d of a chunk
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<_Float16*>(dst + e * AT_VROW) = v[e];
     }
   };
 
@@ -159,22 +140,15 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
   float m = -1e30f, l = 0.f;                       // running row max (raw scores) and row sum, per query = per lane pair
 
   const int nblk = (S + AT_KB - 1) / AT_KB;
-  kdma(0, 0);
-  vload(0, rva);
-  kdma(1, 1);
-  vload(1, rvb);
-  vstore(0, rva);
+  stage_next(0, 0);
+  vstore(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int kcur = 0;                                    // K buffer of the current block (blk % 3)
-  // one block; (rv_next, rv_free) = register sets holding V of block blk+1 / free for block blk+2
-  auto block = [&](int blk, uint4_ (&rv_next)[VCH], uint4_ (&rv_free)[VCH]) {
+  for (int blk = 0; blk < nblk; ++blk) {
     const int cur = blk & 1;
-    const int knext2 = kcur == 0 ? 2 : kcur - 1;   // (blk + 2) % 3
-    kdma(blk + 2, knext2);
-    vload(blk + 2, rv_free);
-    const unsigned char* kb = smem + kcur * AT_K_BYTES;
-    const unsigned char* vb = smem + AT_V_OFF + cur * AT_V_BYTES;
+    if (blk + 1 < nblk) stage_next(blk + 1, cur ^ 1);   // in flight while this block is multiplied
+    const unsigned char* kb = smem + cur * AT_BUF;
+    const unsigned char* vb = kb + AT_K_BYTES;
     if (wave_active) {
       const int key0 = blk * AT_KB;
       // ---- S^T tiles = K (2 x 32 keys) x Q^T: two independent accumulator chains
@@ -249,8 +223,8 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const int d = 32 * dt + lq;
-        vr0[dt] = vb + d * AT_VROW + 8 * hi;
-        vr1[dt] = vb + d * AT_VROW + 16 + 8 * hi;
+        vr0[dt] = vb + d * AT_VROW + (((4 * hi) ^ vswz(d)) << 1);
+        vr1[dt] = vb + d * AT_VROW + (((8 + 4 * hi) ^ vswz(d)) << 1);
       }
       half4 va[2][4], vc[2][4];
       auto vread = [&](int ks, int slot) {
@@ -273,23 +247,14 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
         }
       }
     }
-    vstore(cur ^ 1, rv_next);                      // V of block blk+1 (loaded one iteration ago) -> the other V^T image
-    // K of block blk+1 (2 DMA per wave, issued one iteration ago) must have landed; this iteration's 2 + 2 may fly on
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (blk + 1 < nblk) vstore(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K pieces of the next block have landed
     __syncthreads();
-    kcur = kcur == 2 ? 0 : kcur + 1;
-  };
-  static_assert(KPW + VCH == 4, "the counted wait above assumes 2 K pieces + 2 V chunks per wave and block");
-  for (int blk = 0; blk < nblk; blk += 2) {
-    block(blk, rvb, rva);
-    if (blk + 1 < nblk) block(blk + 1, rva, rvb);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stray prefetches past the last block must not land in the output tiles
-  __syncthreads();
 
   // ---- normalise, transpose through a wave-private LDS tile [32 queries][128 d] (16-byte chunks XORed with q & 15),
   // store whole 256-byte rows
-  unsigned char* tile = smem + wid * (32 * 256);   // 8 x 8 KiB laid over the K / V buffers (everyone is past the last barrier)
+  unsigned char* tile = smem + wid * (32 * 256);   // 8 x 8 KiB inside the two buffers (everyone is past the last barrier)
   if (wave_active) {
     const float inv = 1.0f / l;
 #pragma unroll
