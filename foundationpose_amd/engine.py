@@ -13,7 +13,6 @@ What is left to PyTorch are the tiny N-row tensors after the token mean (head li
 Linear) and elementwise glue (2.6 % of the GPU time, profiles/README.md).
 precision='fp32' is the parity configuration: all torch ops, fp32, no autocast.
 """
-import math
 import os
 
 import torch

@@ -5,7 +5,6 @@
 libfp_amd.so (fp_crop_windows, fp_render_crops, fp_warp_crops, fp_pose_update) around the network plan, with
 no host round trip inside the loop.
 """
-import logging
 import os
 
 import numpy as np
@@ -17,7 +16,6 @@ from .engine import RefinePlan
 from .h5_dataset import PoseRefinePairH5Dataset
 from .pose_dataset import BatchPoseData
 from .refine_network import RefineNet
-from .weights import DEFAULT_REFINE_CFG
 
 _REFINE_DEFAULTS = dict(use_normal=False, use_mask=False, use_BN=False, c_in=4, crop_ratio=1.2, n_view=1,
                         trans_rep="tracknet", rot_rep="axis_angle", zfar=3, normalize_xyz=False, normal_uint8=False)

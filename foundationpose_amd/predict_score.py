@@ -1,5 +1,4 @@
 """ScorePredictor -- drop-in for learning/training/predict_score.py:117-226."""
-import logging
 
 import numpy as np
 import torch

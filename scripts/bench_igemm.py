@@ -1,5 +1,5 @@
 """Per-layer throughput of fp_igemm_f16_fwd at the bench shapes (N=252) + the other hand-written kernels.  Debug/profiling aid."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from foundationpose_amd import ops
