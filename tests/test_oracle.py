@@ -179,3 +179,62 @@ def test_attention_core_definition_matches_nn_multiheadattention():
         ctx = (torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, S, H * hd)
         got = att.out_proj(ctx)
     assert (got - want).abs().max().item() < 1e-5
+
+
+def test_attention_kernel_lane_bookkeeping_in_numpy():
+    """The index scheme of csrc/attention.hip replayed with a numpy model of v_mfma_f32_32x32x16_f16 (A lane l holds
+    A[l&31][8(l>>5)+i], B lane l holds B[8(l>>5)+i][l&31], D lane l reg r = D[(r&3)+8(r>>2)+4(l>>5)][l&31]): scores
+    computed transposed, probabilities fed to the second product straight from the registers they are born in, V^T read
+    with the matching key permutation.  Guards the permutation documented at the top of the kernel."""
+    rng = np.random.default_rng(0)
+    nq, nk, d = 32, 64, 128                     # one query tile, one 64-key block
+
+    def mfma(a_frag, b_frag, acc):              # a_frag, b_frag: (64 lanes, 8); acc: (64 lanes, 16)
+        A = np.zeros((32, 16)); B = np.zeros((16, 32))
+        for l in range(64):
+            A[l & 31, 8 * (l >> 5):8 * (l >> 5) + 8] = a_frag[l]
+            B[8 * (l >> 5):8 * (l >> 5) + 8, l & 31] = b_frag[l]
+        D = A @ B
+        out = acc.copy()
+        for l in range(64):
+            for r in range(16):
+                out[l, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+        return out
+
+    Q, K, V = rng.standard_normal((nq, d)), rng.standard_normal((nk, d)), rng.standard_normal((nk, d))
+    lanes = np.arange(64); lq, hi = lanes & 31, lanes >> 5
+    # S^T tiles: A = K rows (key = 32 sb + lane & 31), B = Q rows (query = lane & 31), k = d
+    s = [np.zeros((64, 16)), np.zeros((64, 16))]
+    for sb in range(2):
+        for kk in range(8):
+            kf = np.stack([K[32 * sb + lq[l], 16 * kk + 8 * hi[l]:16 * kk + 8 * hi[l] + 8] for l in range(64)])
+            qf = np.stack([Q[lq[l], 16 * kk + 8 * hi[l]:16 * kk + 8 * hi[l] + 8] for l in range(64)])
+            s[sb] = mfma(kf, qf, s[sb])
+    # lane l, reg r of tile sb is the score of query l&31 against key 32 sb + (r&3) + 8(r>>2) + 4(l>>5)
+    S_ref = Q @ K.T
+    for sb in range(2):
+        for l in (0, 17, 40, 63):
+            for r in range(16):
+                assert abs(s[sb][l, r] - S_ref[l & 31, 32 * sb + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]) < 1e-9
+    # softmax over the 64 keys of a query = the lane's 32 registers + those of lane l ^ 32
+    m = np.maximum(np.max(s[0], 1), np.max(s[1], 1)); m = np.maximum(m, m[lanes ^ 32])
+    p = [np.exp(s[0] - m[:, None]), np.exp(s[1] - m[:, None])]
+    rs = p[0].sum(1) + p[1].sum(1); rs = rs + rs[lanes ^ 32]
+    # O^T += V^T P^T: k-step ks of the block = registers 8(ks&1)..+7 of tile ks>>1; the V^T fragment of lane (d, hi) is
+    # keys 16 ks + 4 hi + {0..3} and 16 ks + 8 + 4 hi + {0..3}
+    o = [np.zeros((64, 16)) for _ in range(4)]
+    for ks in range(4):
+        pf = p[ks >> 1][:, 8 * (ks & 1):8 * (ks & 1) + 8]
+        for dt in range(4):
+            vf = np.zeros((64, 8))
+            for l in range(64):
+                k0 = 16 * ks + 4 * hi[l]
+                keys = list(range(k0, k0 + 4)) + list(range(k0 + 8, k0 + 12))
+                vf[l] = V[keys, 32 * dt + lq[l]]
+            o[dt] = mfma(vf, pf, o[dt])
+    want = (np.exp(S_ref - S_ref.max(1, keepdims=True)) / np.exp(S_ref - S_ref.max(1, keepdims=True)).sum(1, keepdims=True)) @ V
+    for dt in range(4):
+        for l in range(64):
+            for r in range(16):
+                dd = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+                assert abs(o[dt][l, r] / rs[l] - want[l & 31, dd]) < 1e-9
