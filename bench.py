@@ -3,9 +3,21 @@
 
 A step = one pass of the hot path for one object and one frame: R=5 refine iterations (crop windows -> fused
 rasteriser -> observed crop -> RefineNet -> pose update) + one score pass (-> ScoreNet -> ranking), inputs resident
-in HBM (BASELINE.json configs[1]).  With --gpus N every rank owns one object (configs[3]) and the
-per-object {scores, refined poses} records are exchanged with ONE RCCL all-gather per step; per-GPU work is fixed
-(weak scaling).  Rank 0 prints one JSON line.
+in HBM (BASELINE.json configs[1]).
+
+Multi-GPU (one process per GPU, RCCL):
+  --mode object (default; BASELINE configs[3]): every rank owns one object and its 252 hypotheses; the per-object
+      {scores, refined poses} records are exchanged with ONE all-gather per step; per-GPU work is fixed (weak scaling).
+  --mode hypothesis: the 252 hypotheses of ONE object are sharded over the ranks (dist.register_hypothesis_parallel):
+      refinement is embarrassingly parallel, the scorer's cross-hypothesis attention is the one exchange step
+      (ONE all-gather of [feature | pose]); total work is fixed (strong scaling).
+`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks on
+127.0.0.1 and fails loudly when the node has fewer than N GPUs; under a launcher (WORLD_SIZE set) --gpus must equal
+the world size.  Rank 0 prints one JSON line.
+
+The headline (`value`, `ms_per_step`) is timed over --steps steps with nothing but the product on the stream; the
+per-kernel table (`kernels`, `roofline`) comes from a SECOND pass of the same length with two HIP events around every
+entry point (ops.KernelTimers), outside the timed region.
 """
 import argparse
 import json
@@ -27,7 +39,7 @@ SCORE_GFLOP_PER_HYP = 21.938
 SCORE_GFLOP_CROSS_252 = 0.659
 # roofline that bounds each hand-written kernel (DESIGN.md "Kernels")
 KERNEL_BOUND = {"fp_render_crops": "hbm", "fp_warp_crops": "hbm", "fp_conv7x7s2_bn_relu_fwd": "hbm",
-                "fp_linear_f16_fwd": "mfma", "fp_igemm_f16_fwd": "mfma", "fp_layernorm_f16_fwd": "hbm",
+                "fp_igemm_f16_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
                 "fp_colmean_f16_fwd": "hbm", "fp_attention_f16_fwd": "mfma"}
 
 
@@ -66,8 +78,9 @@ def _log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(n_hyp=128, iters=5):
-    """oracle (C rasteriser/warp with OpenMP + torch-CPU fp32 networks) on BASELINE configs[0]; checker, not product"""
+def cpu_baseline(n_hyp=16, iters=5, reps=3):
+    """BASELINE configs[0] (16 hypotheses, one frame, 5 refine iterations + 1 score pass, no GPU) on the oracle -- C
+    rasteriser/warp with OpenMP + torch-CPU fp32 networks -- repeated `reps` times; checker, not product"""
     from foundationpose_amd import synthetic as syn
     from foundationpose_amd.Utils import euler_matrix, sample_views_icosphere
     from foundationpose_amd.mesh import make_can_mesh
@@ -94,13 +107,30 @@ def cpu_baseline(n_hyp=128, iters=5):
     xyz = oo.depth2xyzmap(d, K)
     op.refine_predict(rcfg, rsd, rgb, d, K, poses[:2], xyz, mnp, diam, iteration=1)  # warm-up
     t0 = time.perf_counter()
-    p = op.refine_predict(rcfg, rsd, rgb, d, K, poses, xyz, mnp, diam, iteration=iters)
-    s = op.score_predict(scfg, ssd, rgb, d, K, p, mnp, diam)
-    np.argsort(-s)
+    for _ in range(reps):
+        p = op.refine_predict(rcfg, rsd, rgb, d, K, poses, xyz, mnp, diam, iteration=iters)
+        s = op.score_predict(scfg, ssd, rgb, d, K, p, mnp, diam)
+        np.argsort(-s)
     dt = time.perf_counter() - t0
-    return dict(value=n_hyp / dt, unit="pose-hypotheses/sec", cores=int(cores), kind="port",
-                sample=f"{n_hyp} hypotheses x ({iters} refine + 1 score), one frame, oracle C raster/warp (OpenMP {oo.num_threads()} thr) "
-                       f"+ torch-CPU fp32 nets ({torch.get_num_threads()} thr), {dt:.2f} s")
+    return dict(value=reps * n_hyp / dt, unit="pose-hypotheses/sec", cores=int(cores), kind="port",
+                sample=f"BASELINE configs[0] x {reps}: {n_hyp} hypotheses x ({iters} refine + 1 score), one frame, oracle C "
+                       f"raster/warp (OpenMP {oo.num_threads()} thr) + torch-CPU fp32 nets ({torch.get_num_threads()} thr), {dt:.2f} s")
+
+
+def _respawn(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run"""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} requested but this node exposes {n_dev} GPU(s); refusing to run fewer ranks")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -111,15 +141,22 @@ def main():
     ap.add_argument("--hyps", type=int, default=252)
     ap.add_argument("--refine-iters", type=int, default=5)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--mode", default="object", choices=["object", "hypothesis"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--nchw", action="store_true", help="disable channels_last activations")
-    ap.add_argument("--no-hip-gemm", action="store_true", help="route conv1/QKV through PyTorch instead of the MFMA kernels")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (instrumented) pass")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _respawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
     import torch.distributed as dist
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs cuda:{local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     use_dist = world > 1 or os.environ.get("FP_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL on one GPU
@@ -127,6 +164,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
 
     from foundationpose_amd import ops
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
@@ -136,18 +174,23 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     N, R = args.hyps, args.refine_iters
+    hyp_mode = args.mode == "hypothesis"
     _log("building scene")
-    sc = build_scene(dev, seed=rank, n_hyp=N)
-    opts = dict(device=dev, precision=args.precision, channels_last=not args.nchw, use_hip_gemm=not args.no_hip_gemm)
+    sc = build_scene(dev, seed=0 if hyp_mode else rank, n_hyp=N)   # hypothesis mode: every rank sees the same object
+    opts = dict(device=dev, precision=args.precision)
     refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), **opts)
     scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), **opts)
     rgb_t = torch.as_tensor(sc["rgb"], device=dev).float().contiguous()
     depth_t = ops.bilateral_filter_depth(ops.erode_depth(torch.as_tensor(sc["depth"], device=dev)))
     xyz_t = ops.depth_to_xyz(depth_t, sc["K"], f64_internal=True)
     poses0 = torch.as_tensor(sc["poses"], device=dev)
-    from foundationpose_amd.dist import gather_object_records
+    from foundationpose_amd.dist import gather_object_records, register_hypothesis_parallel
 
     def step():
+        if hyp_mode:
+            p, s, _ = register_hypothesis_parallel(refiner, scorer, rgb_t, depth_t, sc["K"], poses0, xyz_t, mesh=sc["mesh"],
+                                                   mesh_tensors=sc["gm"], mesh_diameter=sc["diameter"], iteration=R)
+            return torch.cat([s.reshape(-1, 1), p.reshape(-1, 16)], dim=1)[None]   # replicated on every rank
         p, _ = refiner.predict(rgb_t, depth_t, sc["K"], poses0, xyz_t, mesh=sc["mesh"], mesh_tensors=sc["gm"],
                                mesh_diameter=sc["diameter"], iteration=R)
         s, _ = scorer.predict(rgb_t, depth_t, sc["K"], p, mesh=sc["mesh"], mesh_tensors=sc["gm"],
@@ -165,11 +208,9 @@ def main():
         step()
     sync()
     _log("timed region")
-    timers = ops.KernelTimers()
     t0 = time.perf_counter()
-    with timers:
-        for _ in range(args.steps):
-            rec = step()
+    for _ in range(args.steps):
+        rec = step()
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -177,59 +218,72 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     assert torch.isfinite(rec).all()
+    # second, instrumented pass (not part of the headline): per-entry-point HIP events on the launch stream
+    timers = ops.KernelTimers()
+    if rank == 0 and not args.no_kernel_table:
+        _log("instrumented pass")
+    if not args.no_kernel_table:
+        with timers:
+            for _ in range(args.steps):
+                step()
+        sync()
 
+    total_hyps = N if hyp_mode else world * N
     if rank == 0:
-        ksum = timers.summary()
         V, T = sc["gm"]["_handle"].V, sc["gm"]["_handle"].T
-        kern = {}
-        for name, k in ksum.items():
-            ent = dict(calls=k["calls"], avg_ms=round(k["avg_ms"], 5))
-            sec = k["avg_ms"] * 1e-3
-            if k["bytes"] > 0 and sec > 0:
-                ent["algorithmic_bytes"] = int(k["bytes"])
-                ent["GBps"] = k["bytes"] / sec / 1e9
-                ent["frac_hbm"] = ent["GBps"] / HBM_PEAK_GBS
-            if k["flops"] > 0 and sec > 0:
-                ent["algorithmic_flops"] = k["flops"]
-                ent["TFLOPs"] = k["flops"] / sec / 1e12
-                ent["frac_mfma"] = ent["TFLOPs"] / MFMA_PEAK_TFLOPS
-            kern[name] = ent
-        # dominant hand-written kernel = largest total time inside the timed region
-        dom = max((n for n in ksum if n in KERNEL_BOUND), key=lambda n: ksum[n]["calls"] * ksum[n]["avg_ms"])
-        dk, bound = ksum[dom], KERNEL_BOUND[dom]
-        sec = dk["avg_ms"] * 1e-3
-        if bound == "hbm":
-            ach, peak, unit = dk["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-        else:
-            ach, peak, unit = dk["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
-        traffic = measured_traffic(dom)
-        r_ms, w_ms = ksum["fp_render_crops"]["avg_ms"], ksum["fp_warp_crops"]["avg_ms"]
-        stage_bytes = ksum["fp_render_crops"]["bytes"] + ksum["fp_warp_crops"]["bytes"]
-        flops = world * N * (R * REFINE_GFLOP_PER_HYP + SCORE_GFLOP_PER_HYP) + world * SCORE_GFLOP_CROSS_252 * (N / 252.0) ** 2
+        flops = total_hyps * (R * REFINE_GFLOP_PER_HYP + SCORE_GFLOP_PER_HYP) + (1 if hyp_mode else world) * SCORE_GFLOP_CROSS_252 * (N / 252.0) ** 2
         out = {
             "metric": "pose-hypotheses/sec (raster+refine+score), 252 hyp x 160x160 @ 640x480 RGB-D",
-            "value": world * N * args.steps / dt, "unit": "pose-hypotheses/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": total_hyps * args.steps / dt, "unit": "pose-hypotheses/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if hyp_mode else "weak",
             "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: synthetic can (V={V}, T={T}), one 640x480 RGB-D frame per rank, "
                                    f"{N} hypotheses, {R} refine iterations + 1 score pass, 160x160 crops, random-init weights",
-                       "hypotheses_per_gpu": N, "refine_iterations": R,
-                       "parallelism": f"object-parallel x{world}, one RCCL all-gather of [score|pose] records per step"},
-            "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                         "traffic": traffic,
-                         "traffic_note": "HBM-side bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/) of "
-                                         "ONE representative launch of this kernel: the 256->256 3x3 conv at N=252 "
-                                         "(algorithmic 228 MB read + 206 MB written); achieved/avg_launch_ms average all "
-                                         "launches of the step" if dom == "fp_igemm_f16_fwd" else "profiles/traffic.json",
-                         "algorithmic_per_launch": dk["bytes"] if bound == "hbm" else dk["flops"],
-                         "avg_launch_ms": dk["avg_ms"], "launches_timed": dk["calls"]},
-            "stage_raster_crop": {"bytes_per_pass": stage_bytes, "ms_per_pass": r_ms + w_ms,
-                                  "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,
-                                  "frac_of_hbm_peak": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       "hypotheses_per_gpu": (N + world - 1) // world if hyp_mode else N, "refine_iterations": R,
+                       "parallelism": (f"hypothesis-parallel x{world}: {N} hypotheses of one object sharded, one RCCL all-gather of "
+                                       f"[feature|pose] per step" if hyp_mode else
+                                       f"object-parallel x{world}, one RCCL all-gather of [score|pose] records per step")},
             "network_mfma": {"algorithmic_TFLOP_per_step": flops / 1e3, "achieved_TFLOPs": flops / 1e3 / (dt / args.steps),
                              "frac_of_mfma_peak": flops / 1e3 / (dt / args.steps) / (MFMA_PEAK_TFLOPS * world)},
-            "kernels": kern,
         }
+        if not args.no_kernel_table:
+            ksum = timers.summary()
+            kern = {}
+            for name, k in ksum.items():
+                ent = dict(calls=k["calls"], avg_ms=round(k["avg_ms"], 5))
+                sec = k["avg_ms"] * 1e-3
+                if k["bytes"] > 0 and sec > 0:
+                    ent["algorithmic_bytes"] = int(k["bytes"])
+                    ent["GBps"] = k["bytes"] / sec / 1e9
+                    ent["frac_hbm"] = ent["GBps"] / HBM_PEAK_GBS
+                if k["flops"] > 0 and sec > 0:
+                    ent["algorithmic_flops"] = k["flops"]
+                    ent["TFLOPs"] = k["flops"] / sec / 1e12
+                    ent["frac_mfma"] = ent["TFLOPs"] / MFMA_PEAK_TFLOPS
+                kern[name] = ent
+            # dominant hand-written kernel = largest total time inside the instrumented pass
+            dom = max((n for n in ksum if n in KERNEL_BOUND), key=lambda n: ksum[n]["calls"] * ksum[n]["avg_ms"])
+            dk, bound = ksum[dom], KERNEL_BOUND[dom]
+            sec = dk["avg_ms"] * 1e-3
+            if bound == "hbm":
+                ach, peak, unit = dk["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = dk["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+            r_ms, w_ms = ksum["fp_render_crops"]["avg_ms"], ksum["fp_warp_crops"]["avg_ms"]
+            stage_bytes = ksum["fp_render_crops"]["bytes"] + ksum["fp_warp_crops"]["bytes"]
+            out["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                               "traffic": measured_traffic(dom),
+                               "traffic_note": "HBM-side bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/) of "
+                                               "ONE representative launch of this kernel: the 256->256 3x3 conv at N=252 "
+                                               "(algorithmic 228 MB read + 206 MB written); achieved/avg_launch_ms average all "
+                                               "launches of the step" if dom == "fp_igemm_f16_fwd" else "profiles/traffic.json",
+                               "algorithmic_per_launch": dk["bytes"] if bound == "hbm" else dk["flops"],
+                               "avg_launch_ms": dk["avg_ms"], "launches_timed": dk["calls"]}
+            out["stage_raster_crop"] = {"bytes_per_pass": stage_bytes, "ms_per_pass": r_ms + w_ms,
+                                        "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,
+                                        "frac_of_hbm_peak": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()

@@ -27,13 +27,14 @@ SIGNATURES = {
     "fp_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "fp_render_crops": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "fp_warp_crops": (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
-    "fp_pose_update": (ci, [vp, vp, vp, ci, ci, vp, cf, cf, ci, vp, vp]),
-    "fp_conv7x7s2_bn_relu_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
-    "fp_linear_f16_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
-    "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
-    "fp_layernorm_f16_fwd": (ci, [vp, vp, vp, cf, vp, ci, ci, vp]),
-    "fp_colmean_f16_fwd": (ci, [vp, vp, vp, cf, vp, ci, ci, ci, vp]),
-    "fp_attention_f16_fwd": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "fp_pose_update": (ci, [vp, vp, vp, ci, ci, vp, cf, cf, ci, vp, vp, vp, vp]),
+    "fp_conv7x7s2_bn_relu_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "fp_add_pe_f16_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "fp_layernorm_res_fwd": (ci, [vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, ci, ci, vp]),
+    "fp_colmean_f16_fwd": (ci, [vp, vp, vp, vp, cf, vp, ci, ci, ci, vp]),
+    "fp_rows_linear_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "fp_attention_f16_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "fp_cluster_poses": (ci, [cf, cf, vp, ci, vp, ci, vp]),
 }
 

@@ -46,8 +46,11 @@ constexpr int AT_WAVES = 8;                       // query tiles per workgroup: 
                                                   // workgroup, so fewer, larger workgroups halve the LDS-write-bound scatter
 constexpr int AT_THREADS = AT_WAVES * 64;
 
+// qscale > 0 selects the fp16-score policy of the need_weights=True branch of F.multi_head_attention_forward under
+// autocast (score_network.py:73,86): q is multiplied by qscale = sqrt(1/d) and rounded to fp16, the q.k products are
+// rounded to fp16 before the fp32 softmax (c is then log2(e) alone).  qscale == 0: scaled_dot_product_attention.
 __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
-                                                          int S, int H, float c /* log2(e)/sqrt(d) */) {
+                                                          int S, int H, float c /* log2(e)/sqrt(d) | log2(e) */, float qscale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 31, hi = lane >> 5;
@@ -69,6 +72,12 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     const _Float16* src = qp + (size_t)qr * ld + 8 * hi;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const half8*>(src + 16 * kk);
+    if (qscale > 0.f) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[kk][e] = (_Float16)((float)qf[kk][e] * qscale);
+    }
   }
 
   // ---- staging.  K: LDS-DMA (buffer_load ... lds), 1 KiB = 4 keys per wave-instruction, 2 pieces per wave and block;
@@ -169,6 +178,10 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
         __builtin_amdgcn_sched_barrier(0);
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk & 1][0], qf[kk], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk & 1][1], qf[kk], s1, 0, 0, 0);
+      }
+      if (qscale > 0.f) {                          // `bmm` under autocast returns fp16 scores
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = (float)(_Float16)s0[r]; s1[r] = (float)(_Float16)s1[r]; }
       }
       if (key0 + AT_KB > S) {                      // keys past the end of the sequence (last block only)
 #pragma unroll
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
 
 }  // namespace
 
-extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, int H, int head_dim, void* stream) {
+extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, int H, int head_dim, int flags, void* stream) {
   FP_REQUIRE(B >= 0 && S >= 0, "fp_attention_f16_fwd: negative size");
   if (B == 0 || S == 0) return FP_OK;
   FP_REQUIRE(qkv && out, "fp_attention_f16_fwd: NULL tensor");
@@ -292,14 +305,13 @@ extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, in
   FP_REQUIRE(H > 0 && ((((size_t)qkv | (size_t)out) & 15) == 0), "fp_attention_f16_fwd: bad head count / unaligned tensors");
   const long long wgs = (long long)B * H * ((S + 32 * AT_WAVES - 1) / (32 * AT_WAVES));
   FP_REQUIRE(wgs < (1ll << 31), "fp_attention_f16_fwd: too many workgroups");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_f16), hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
-    attr_set = true;
-  }
-  const float c = 1.4426950408889634f / sqrtf((float)head_dim);
+  FP_SET_MAX_LDS(k_attention_f16, AT_LDS);
+  FP_REQUIRE((flags & ~FP_ATT_FP16_SCORES) == 0, "fp_attention_f16_fwd: unknown flags 0x%x", flags);
+  const bool f16s = (flags & FP_ATT_FP16_SCORES) != 0;
+  const float qscale = f16s ? (float)sqrt(1.0 / (double)head_dim) : 0.f;
+  const float c = f16s ? 1.4426950408889634f : 1.4426950408889634f / sqrtf((float)head_dim);
   hipLaunchKernelGGL(k_attention_f16, dim3((unsigned)wgs), dim3(AT_THREADS), AT_LDS, (hipStream_t)stream,
-                     (const _Float16*)qkv, (_Float16*)out, S, H, c);
+                     (const _Float16*)qkv, (_Float16*)out, S, H, c, qscale);
   FP_CHECK_LAUNCH("fp_attention_f16_fwd");
   return FP_OK;
 }

@@ -11,7 +11,8 @@
 //     buffered: the patch of band t+1 is in flight while band t is multiplied;
 //   * B-fragment of a lane = 8 consecutive input pixels of one (c, ky) row starting at 2*ox - 3: five conflict-free
 //     ds_read_b32 + four v_alignbit (the run starts on an odd element), no im2col, no index table;
-//   * D[channel][pixel] accumulators get BN(scale, shift) + ReLU in fp32, are transposed through a wave-private
+//   * D[channel][pixel] accumulators go through the reference's autocast op sequence -- conv output rounded to fp16,
+//     + bias (fp16), eval BatchNorm (fp32 statistics) rounded to fp16, ReLU -- are transposed through a wave-private
 //     swizzled LDS tile and leave as 16-byte stores: 128 contiguous bytes per pixel (all 64 channels).
 #include <hip/hip_fp16.h>
 #include "fp_common.h"
@@ -33,7 +34,8 @@ __device__ __attribute__((aligned(16))) const unsigned int c1_zero16[4] = {0u, 0
 struct Conv1Params {
   const _Float16* X;     // (B, 6, Hin, Win)
   const _Float16* W;     // (64, 294)
-  const float* scale;    // (64)
+  const float* bias;     // (64) conv bias (fp16-representable values) or null
+  const float* scale;    // (64) eval BatchNorm as x * scale + shift, or null
   const float* shift;    // (64)
   _Float16* Y;           // (B, Hout + 2*pad, Wout + 2*pad, 64)
   int B, Hin, Win, Hout, Wout, pad;
@@ -85,15 +87,17 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
     for (int e = 0; e < 7; ++e) wf[ks][e] = w[e];
     wf[ks][7] = (_Float16)0.f;
   }
-  // BN scale / shift of this lane's 16 output channels: channel = hsel*32 + 8*g4 + 4*kh + e
-  float sc[4][4], sh[4][4];
+  // bias / BN scale / shift of this lane's 16 output channels: channel = hsel*32 + 8*g4 + 4*kh + e
+  float bi[4][4], sc[4][4], sh[4][4];
+  const bool has_bn = p.scale != nullptr;
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int chn = hsel * 32 + 8 * g4 + 4 * kh + e;
-      sc[g4][e] = p.scale[chn];
-      sh[g4][e] = p.shift[chn];
+      bi[g4][e] = p.bias ? p.bias[chn] : 0.f;
+      sc[g4][e] = has_bn ? p.scale[chn] : 1.f;
+      sh[g4][e] = has_bn ? p.shift[chn] : 0.f;
     }
 
   const int band_px = C1_ROWS * p.Wout;
@@ -136,12 +140,18 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
         const half8 fb = __builtin_bit_cast(half8, fv);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], fb, acc, 0, 0, 0);
       }
-      // ---- epilogue: BN + ReLU, transpose through the wave-private tile (32 px x 64 B), 16-byte stores
+      // ---- epilogue: fp16(conv) + bias -> fp16 -> BN -> fp16 -> ReLU (the autocast op sequence of
+      //      nn.Conv2d / nn.BatchNorm2d / nn.ReLU), transpose through the wave-private tile (32 px x 64 B), 16-byte stores
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         half4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (_Float16)fmaxf(fmaf(acc[g4 * 4 + e], sc[g4][e], sh[g4][e]), 0.f);
+        for (int e = 0; e < 4; ++e) {
+          float t = (float)(_Float16)acc[g4 * 4 + e];
+          t = (float)(_Float16)(t + bi[g4][e]);
+          if (has_bn) t = (float)(_Float16)fmaf(t, sc[g4][e], sh[g4][e]);
+          v[e] = (_Float16)fmaxf(t, 0.f);
+        }
         const int chl = 8 * g4 + 4 * kh;                 // channel within this wave's 32
         const int chunk = (chl >> 3) ^ (px & 3);
         *reinterpret_cast<half4*>(etile + px * 64 + (chunk << 4) + ((chl & 4) << 1)) = v;
@@ -165,33 +175,43 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
   }
 }
 
-int fp_conv1_nhwc_launch(const void* x, const void* w, const float* scale, const float* shift, void* y, int B, int Hin,
-                         int Win, int pad, hipStream_t stream) {
+extern "C" int fp_conv7x7s2_bn_relu_fwd(const void* x, const void* w, const float* bias, const float* bn_scale,
+                                        const float* bn_shift, void* y, int B, int Hin, int Win, int pad, void* stream) {
+  FP_REQUIRE(B >= 0, "fp_conv7x7s2_bn_relu_fwd: B < 0");
+  if (B == 0) return FP_OK;
+  FP_REQUIRE(x && w && y, "fp_conv7x7s2_bn_relu_fwd: NULL tensor");
+  FP_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fp_conv7x7s2_bn_relu_fwd: bn_scale and bn_shift go together");
+  FP_REQUIRE(Hin > 0 && Win > 0 && Hin % 2 == 0 && Win % 8 == 0 && Win <= C1_MAXW,
+             "fp_conv7x7s2_bn_relu_fwd: input %dx%d unsupported (even height, width a multiple of 8 and <= %d)", Hin, Win, C1_MAXW);
+  FP_REQUIRE(pad == 0 || pad == 1, "fp_conv7x7s2_bn_relu_fwd: pad must be 0 or 1");
+  FP_REQUIRE((((size_t)x | (size_t)y) & 15) == 0, "fp_conv7x7s2_bn_relu_fwd: tensors must be 16-byte aligned");
   Conv1Params p;
-  p.X = (const _Float16*)x; p.W = (const _Float16*)w; p.scale = scale; p.shift = shift; p.Y = (_Float16*)y;
+  p.X = (const _Float16*)x; p.W = (const _Float16*)w; p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.Y = (_Float16*)y;
   p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hin / 2; p.Wout = Win / 2; p.pad = pad;
   p.bands_per_image = fp_cdiv(p.Hout, C1_ROWS);
+  FP_REQUIRE((long long)B * p.bands_per_image < (1ll << 31), "fp_conv7x7s2_bn_relu_fwd: batch too large");
   p.total_bands = B * p.bands_per_image;
   p.PW = Win + 16;
   const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;
   const size_t lds = 2 * (size_t)patch_bytes + 8 * 2048;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      fp_set_error("fp_conv7x7s2_bn_relu_fwd: cannot query the device");
-      return FP_ERR_LAUNCH;
-    }
-    n_cu = prop.multiProcessorCount;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv7x7s2_nhwc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
   if (lds > 160 * 1024) {
     fp_set_error("fp_conv7x7s2_bn_relu_fwd: input width %d needs %zu bytes of LDS", Win, lds);
     return FP_ERR_UNSUPPORTED;
   }
-  const int grid = p.total_bands < n_cu ? p.total_bands : n_cu;
-  hipLaunchKernelGGL(k_conv7x7s2_nhwc, dim3(grid), dim3(C1_THREADS), lds, stream, p);
-  FP_CHECK_LAUNCH("fp_conv7x7s2_bn_relu_fwd(nhwc)");
+  int dev = 0;
+  static int n_cu[64] = {0};
+  (void)hipGetDevice(&dev);
+  if (n_cu[dev & 63] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      fp_set_error("fp_conv7x7s2_bn_relu_fwd: cannot query the device");
+      return FP_ERR_LAUNCH;
+    }
+    n_cu[dev & 63] = prop.multiProcessorCount;
+  }
+  FP_SET_MAX_LDS(k_conv7x7s2_nhwc, 160 * 1024);
+  const int grid = p.total_bands < n_cu[dev & 63] ? p.total_bands : n_cu[dev & 63];
+  hipLaunchKernelGGL(k_conv7x7s2_nhwc, dim3(grid), dim3(C1_THREADS), lds, (hipStream_t)stream, p);
+  FP_CHECK_LAUNCH("fp_conv7x7s2_bn_relu_fwd");
   return FP_OK;
 }

@@ -1,0 +1,260 @@
+// k_conv_sw -- shifted-window 3x3 convolution (stride 1, pad 1) on the ping-pong schedule of igemm_pp.hip: the kernel
+// behind fp_igemm_f16_fwd for the twelve ResnetBasicBlock convolutions of each encoder (network_modules.py:73-111;
+// refine_network.py:40-49, score_network.py:39-48), where input and output share one padded pixel grid.
+//
+// Why: as an implicit GEMM with k = (tap, ci) every workgroup fetches each of its activation rows nine times, once per
+// tap (measured on the 256->256 layer: 1.33 GB moved for 0.43 GB of tensors, and an LDS-DMA issue rate that keeps the
+// memory cluster of the ping-pong loop longer than its MFMA cluster).  Here the k order is (channel chunk,
+// tap): per 32-channel chunk ONE patch of the padded input -- the tile's 256 output pixels plus a halo of Wp+1 pixels
+// on either side, as one contiguous run of the padded NHWC grid -- is staged in LDS, and the nine taps read it at a row
+// shift of ky*Wp + kx.  Rows of the GEMM stay the true output pixels (no border work, same epilogue): a lane's fragment
+// row for tap (ky,kx) is its pixel's position in the patch + the shift.
+//
+// Operand traffic per k-step drops from (256 + BN) rows to BN rows + 1/9 patch; LDS-DMA instructions per wave and
+// k-step from 4 to 2.4 (BN = 256) and from 3 to 1.4 (BN = 128).
+//
+// LDS: two patch buffers of 512 rows x 64 B (double buffered across chunks) + a ring of 4 weight stages of BN x 64 B;
+// 64-byte rows XOR-swizzled as in igemm_pp.hip (chunk ^ ((row >> 2) & 3), a bijection of row mod 16, so 32 consecutive
+// patch rows at ANY offset are conflict-free for ds_read_b128).  Schedule: two groups of 4 waves one cluster apart,
+// a k-step = memory cluster (12 fragment reads + this step's LDS-DMA) | barrier | 16 MFMAs | barrier; weights are
+// prefetched three k-steps ahead, the next chunk's patch is requested one piece per wave at taps 0-3 of the current chunk.
+#include <hip/hip_fp16.h>
+#include <type_traits>
+#include "igemm_common.h"
+#include "igemm_epilogue.h"
+
+namespace {
+
+constexpr int SW_BM = 256, SW_BK = 32, SW_NSTW = 4;
+constexpr int SW_PROWS = 512;                       // patch rows per buffer: 32 LDS-DMA instructions of 16 rows
+constexpr int SW_PATCH_BYTES = SW_PROWS * SW_BK * 2;
+
+template <int N>
+__device__ __forceinline__ void sw_wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// padded-grid index of tap (0,0) of output pixel m: (b * Hp + oy) * Wp + ox
+__device__ __forceinline__ int sw_q(const IgemmGeom& g, int m) {
+  const int b = ig_fastdiv(m, g.mulP, g.shrP);
+  const int r = m - b * g.HoWo;
+  const int oy = ig_fastdiv(r, g.mulW, g.shrW);
+  const int ox = r - oy * g.Wo;
+  return (b * g.Hp + oy) * g.Wp + ox;
+}
+
+template <int BN, int TM>
+__global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
+  constexpr int BM = SW_BM, BK = SW_BK, NW = 8, THREADS = 512;
+  constexpr int NWN = BN / 64;
+  static_assert((BM / (32 * TM)) * NWN == NW, "8 waves");
+  constexpr int ROWB = BK * 2;                      // 64-byte LDS rows
+  constexpr int W_BYTES = BN * ROWB;
+  constexpr int WI = BN / 16 / NW;                  // weight LDS-DMA instructions per wave and k-step (16 rows each)
+  constexpr int PI = SW_PROWS / 16 / NW;            // patch instructions per wave and chunk (4): one at each of taps 0..3
+  static_assert(WI >= 1 && PI == 4, "tile shape");
+  constexpr int STAGES_BYTES = 2 * SW_PATCH_BYTES + SW_NSTW * W_BYTES;
+  constexpr int LDS_MAIN = ig_lds_main<BM, BN>(STAGES_BYTES);
+  auto swz = [](int row) { return (row >> 2) & 3; };
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const patch = smem;                              // 2 x SW_PATCH_BYTES
+  unsigned char* const wring = smem + 2 * SW_PATCH_BYTES;         // SW_NSTW x W_BYTES
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;
+  const int wm = wid / NWN, wn = wid - wm * NWN;
+  float* bias_lds = reinterpret_cast<float*>(smem + LDS_MAIN);
+
+  // XCD-aware tile order (as igemm.hip): neighbouring pixel tiles (overlapping halos) and the channel tiles of one pixel
+  // tile run on the same XCD
+  const int tiles_n = p.N / BN;
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (qd8 + 1) : r8 * (qd8 + 1) + (xcd - r8) * qd8) + loc;
+  const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int Cin = p.Cin, Ktot = 9 * Cin, Wp = p.in.Wp;
+  const int ncc = Cin / BK;
+  ig_bias_to_lds(p, n0, bias_lds, wid, lane);
+
+  // ---- DMA sources.  Patch row R <-> padded pixel q0 + R (clamped into the tensor: clamped rows are never read by a
+  // row that is stored).  Wave w owns patch instructions 4w..4w+3 (16 rows each).
+  const int q0 = sw_q(p.in, m0);
+  const int qmax = (p.M / p.in.HoWo) * p.in.Hp * Wp - 1;
+  unsigned poff32[PI], woff32[WI];
+#pragma unroll
+  for (int j = 0; j < PI; ++j) {
+    const int row = (wid * PI + j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ swz(row);
+    int q = q0 + row;
+    q = q < qmax ? q : qmax;
+    poff32[j] = (unsigned)(((long long)q * p.in.cstride + p.in.coff + c * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    const int row = (wid * WI + j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ swz(row);
+    woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Wt), 0, 0x7FFFFFFF, 0x00020000);
+
+  auto stage_patch = [&](int cc, int j) {          // piece j (0..3) of this wave of the patch of chunk cc
+    unsigned char* dst = patch + (cc & 1) * SW_PATCH_BYTES + (wid * PI + j) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, (int)poff32[j],
+                                             cc * (BK * 2), 0, 0);
+  };
+  auto stage_w = [&](int cc, int tap, int slot) {  // weight columns [tap*Cin + cc*32, +32) of the tile's BN rows
+    const int wsoff = (tap * Cin + cc * BK) * 2;
+    unsigned char* dst = wring + slot * W_BYTES + wid * (WI * 1024);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16,
+                                               (int)woff32[j], wsoff, 0, 0);
+  };
+
+  float16_ acc[2][TM];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addressing: the lane's pixel rows (position in the patch at tap (0,0)) and its weight rows
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int arow[TM], w_off[2][2];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    int m = m0 + wm * (32 * TM) + t * 32 + frow;
+    m = m < p.M ? m : p.M - 1;
+    arow[t] = sw_q(p.in, m) - q0;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rw = wn * 64 + t * 32 + frow;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) w_off[t][kk] = rw * ROWB + (((2 * kk + fhalf) ^ swz(rw)) << 4);
+  }
+
+  // ---- prologue: patch(0) + W of k-steps 0..2 in flight; patch(0) and W(0) landed and visible
+#pragma unroll
+  for (int j = 0; j < PI; ++j) stage_patch(0, j);
+  stage_w(0, 0, 0);
+  stage_w(0, 1, 1);
+  stage_w(0, 2, 2);
+  sw_wait_vm<2 * WI>();
+  __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();           // group 1 sits out interval 0
+
+  half8 fa[2][TM], fw[2][2];
+  // one k-step = (chunk cc, tap T).  LAST: cc is the last chunk (no next patch; the weight prefetch runs dry).
+  // vmcnt bookkeeping (loads retire in order): this wave's pieces of W(s+1) must have landed when it leaves the memory
+  // cluster; younger and allowed in flight are W(s+2), W(s+3) and the patch pieces issued in this and the previous step.
+  auto kstep = [&](int cc, auto tap_c, auto last_c) {
+    constexpr int T = decltype(tap_c)::value;
+    constexpr bool LAST = decltype(last_c)::value;
+    constexpr int ky = T / 3, kx = T - 3 * ky;
+    const int s = cc * 9 + T;
+    const unsigned char* pb = patch + (cc & 1) * SW_PATCH_BYTES;
+    const unsigned char* wb = wring + (s & (SW_NSTW - 1)) * W_BYTES;
+    const int shift = ky * Wp + kx;
+    // ---- memory cluster
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      int ar = arow[t];
+      asm volatile("" : "+v"(ar));                 // recompute the 5-instruction address per tap: hoisting the 36 tap
+                                                   // addresses out of the chunk loop (loop invariant) spills registers
+      const int pr = ar + shift;
+      const int a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+      fa[0][t] = *reinterpret_cast<const half8*>(pb + a0);
+      fa[1][t] = *reinterpret_cast<const half8*>(pb + (a0 ^ 32));
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fw[kk][t] = *reinterpret_cast<const half8*>(wb + w_off[t][kk]);
+    if constexpr (!LAST) {
+      if constexpr (T < PI) stage_patch(cc + 1, T);
+      // k-step s+3 = (cc, T+3) or (cc+1, T-6)
+      if constexpr (T + 3 < 9) stage_w(cc, T + 3, (s + 3) & (SW_NSTW - 1));
+      else stage_w(cc + 1, T - 6, (s + 3) & (SW_NSTW - 1));
+      constexpr int NP = (T == 0 || T == 4) ? 1 : ((T >= 1 && T <= 3) ? 2 : 0);
+      sw_wait_vm<2 * WI + NP>();
+    } else {
+      if constexpr (T + 3 < 9) stage_w(cc, T + 3, (s + 3) & (SW_NSTW - 1));
+      // at T == 0 the previous step (tap 8 of the chunk before) issued no patch piece, and the last chunk issues none
+      constexpr int NYOUNGER = T <= 5 ? 2 : (T == 6 ? 1 : 0);
+      sw_wait_vm<NYOUNGER * WI>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired before the buffers can be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- compute cluster
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto chunk = [&](int cc, auto last_c) {
+    kstep(cc, std::integral_constant<int, 0>{}, last_c);
+    kstep(cc, std::integral_constant<int, 1>{}, last_c);
+    kstep(cc, std::integral_constant<int, 2>{}, last_c);
+    kstep(cc, std::integral_constant<int, 3>{}, last_c);
+    kstep(cc, std::integral_constant<int, 4>{}, last_c);
+    kstep(cc, std::integral_constant<int, 5>{}, last_c);
+    kstep(cc, std::integral_constant<int, 6>{}, last_c);
+    kstep(cc, std::integral_constant<int, 7>{}, last_c);
+    kstep(cc, std::integral_constant<int, 8>{}, last_c);
+  };
+  for (int cc = 0; cc + 1 < ncc; ++cc) chunk(cc, std::false_type{});
+  chunk(ncc - 1, std::true_type{});
+  if (!grp) __builtin_amdgcn_s_barrier();          // group 0 waits out group 1's last compute cluster
+  __syncthreads();
+  ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
+}
+
+template <int BN, int TM>
+int sw_launch(const IgemmParams& p, hipStream_t stream) {
+  constexpr int LDS = ig_lds_main<SW_BM, BN>(2 * SW_PATCH_BYTES + SW_NSTW * BN * SW_BK * 2) + IG_BIAS_LDS;
+  static_assert(LDS <= 160 * 1024, "does not fit the 160 KiB LDS");
+  const long long tiles = (long long)fp_cdiv(p.M, SW_BM) * (p.N / BN);
+  FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
+  FP_SET_MAX_LDS((k_conv_sw<BN, TM>), LDS);
+  hipLaunchKernelGGL((k_conv_sw<BN, TM>), dim3((unsigned)tiles), dim3(512), LDS, stream, p);
+  FP_CHECK_LAUNCH("fp_igemm_f16_fwd(conv_sw)");
+  return FP_OK;
+}
+
+}  // namespace
+
+// The patch of a tile is the run of padded pixels from tap (0,0) of its first output pixel to tap (2,2) of its last:
+// 255 + 2 per image-row crossing + 2 Wp + 2 per image crossing + 2 Wp + 3.  It has to fit SW_PROWS rows.
+bool fp_conv3x3_sw_applicable(const IgemmParams& p) {
+  const IgemmGeom& g = p.in;
+  if (p.taps != 9 || g.stride != 1 || g.off != 0 || g.bsplit != 0) return false;
+  if (g.HoWo % g.Wo != 0 || g.Wp != g.Wo + 2 || g.Hp != g.HoWo / g.Wo + 2) return false;
+  if (p.M % g.HoWo != 0 || p.M < 2 * SW_BM) return false;
+  if (p.Cin % SW_BK != 0 || p.N % 128 != 0) return false;
+  const long long bytes = (long long)(p.M / g.HoWo) * g.Hp * g.Wp * g.cstride * 2;
+  if (bytes >= (1ll << 31)) return false;           // 32-bit byte offsets in the LDS-DMA source addresses
+  const int row_cross = (SW_BM - 1) / g.Wo + 1, img_cross = (SW_BM - 1) / g.HoWo + 1;
+  const int span = (SW_BM - 1) + 2 * row_cross + (2 * g.Wp + 2) * img_cross + 2 * g.Wp + 3;
+  return span <= SW_PROWS;
+}
+
+int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream) {
+  if ((p.N % 256) == 0) return sw_launch<256, 4>(p, stream);
+  return sw_launch<128, 2>(p, stream);
+}

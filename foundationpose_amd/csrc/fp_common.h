@@ -39,3 +39,17 @@ struct fp_k9 { float v[9]; };
 struct fp_k9d { double v[9]; };
 
 static inline int fp_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device).
+// Use as FP_SET_MAX_LDS(kernel_symbol, bytes) right before the launch.
+#define FP_SET_MAX_LDS(kernel, bytes)                                                                              \
+  do {                                                                                                             \
+    static unsigned long long done_ = 0ull;                                                                        \
+    int dev_ = 0;                                                                                                  \
+    (void)hipGetDevice(&dev_);                                                                                     \
+    if (!((done_ >> (dev_ & 63)) & 1ull)) {                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (bytes));                                                                          \
+      done_ |= 1ull << (dev_ & 63);                                                                                \
+    }                                                                                                              \
+  } while (0)

@@ -135,7 +135,8 @@ struct fp_f3 { float v[3]; };
 
 __global__ void k_pose_update(const float* __restrict__ trans, const float* __restrict__ rot,
                               const float* __restrict__ poses_in, int rot_rep, int normalize_xyz, fp_f3 tn,
-                              float rot_normalizer, float mesh_diameter, int N, float* __restrict__ poses_out) {
+                              float rot_normalizer, float mesh_diameter, int N, float* __restrict__ poses_out,
+                              float* __restrict__ trans_delta_out, float* __restrict__ rot_delta_out) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float dt[3];
@@ -190,6 +191,18 @@ __global__ void k_pose_update(const float* __restrict__ trans, const float* __re
   o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) O[k] = o[k];
+  // what the reference keeps as last_trans_update / last_rot_update (predict_pose_refine.py:238-239): the metric
+  // translation delta and the applied rotation so3_exp_map(w)^T
+  if (trans_delta_out) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) trans_delta_out[n * 3 + c] = dt[c];
+  }
+  if (rot_delta_out) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rot_delta_out[(size_t)n * 9 + r * 3 + c] = R[c * 3 + r];
+  }
 }
 
 // ---------------------------------------------------------------- C ABI
@@ -238,7 +251,8 @@ extern "C" int fp_crop_windows(const float* poses, const double* K, double mesh_
 
 extern "C" int fp_pose_update(const float* trans, const float* rot, const float* poses_in, int rot_rep,
                               int normalize_xyz, const float* trans_normalizer, float rot_normalizer,
-                              float mesh_diameter, int N, float* poses_out, void* stream) {
+                              float mesh_diameter, int N, float* poses_out, float* trans_delta_out, float* rot_delta_out,
+                              void* stream) {
   FP_REQUIRE(N >= 0, "fp_pose_update: N < 0");
   if (N == 0) return FP_OK;
   FP_REQUIRE(trans && rot && poses_in && poses_out, "fp_pose_update: NULL tensor");
@@ -246,7 +260,7 @@ extern "C" int fp_pose_update(const float* trans, const float* rot, const float*
   fp_f3 tn = {{1.f, 1.f, 1.f}};
   if (trans_normalizer) { tn.v[0] = trans_normalizer[0]; tn.v[1] = trans_normalizer[1]; tn.v[2] = trans_normalizer[2]; }
   hipLaunchKernelGGL(k_pose_update, dim3(fp_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, trans, rot, poses_in,
-                     rot_rep, normalize_xyz, tn, rot_normalizer, mesh_diameter, N, poses_out);
+                     rot_rep, normalize_xyz, tn, rot_normalizer, mesh_diameter, N, poses_out, trans_delta_out, rot_delta_out);
   FP_CHECK_LAUNCH("fp_pose_update");
   return FP_OK;
 }

@@ -29,8 +29,9 @@
 #include "igemm_common.h"
 #include "igemm_epilogue.h"
 
-int fp_conv3x3s1_launch(const IgemmParams& p, int B, hipStream_t stream);   // conv3x3.hip
 int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream);   // igemm_pp.hip
+int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream);               // conv_sw.hip (shifted-window 3x3)
+bool fp_conv3x3_sw_applicable(const IgemmParams& p);
 
 // Workgroup tile BM (pixels) x BN (channels) x 64 (k); every wave owns (32*TM) x 64 outputs as TM x 2
 // v_mfma_f32_32x32x16_f16 tiles; NST LDS stages (prefetch distance NST-1 k-steps, counted vmcnt + raw s_barrier).
@@ -197,12 +198,7 @@ static int ig_launch(const IgemmParams& p, hipStream_t stream) {
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_f16<BM, BN, TM, NST, BK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  FP_SET_MAX_LDS((k_igemm_f16<BM, BN, TM, NST, BK>), LDS);
   hipLaunchKernelGGL((k_igemm_f16<BM, BN, TM, NST, BK>), dim3((unsigned)tiles), dim3(THREADS), LDS, stream, p);
   FP_CHECK_LAUNCH("fp_igemm_f16_fwd");
   return FP_OK;
@@ -228,8 +224,9 @@ static IgemmGeom ig_geom(const fp_igemm_geom* g) {
 }
 
 extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, const void* w, const float* bias,
-                                const void* residual, const fp_igemm_geom* r_geom, void* y, const fp_igemm_geom* y_geom,
-                                int M, int N, int Cin, int taps, int relu, void* stream) {
+                                const float* bn_scale, const float* bn_shift, const void* residual,
+                                const fp_igemm_geom* r_geom, void* y, const fp_igemm_geom* y_geom, int M, int N, int Cin,
+                                int taps, int flags, void* stream) {
   FP_REQUIRE(M >= 0, "fp_igemm_f16_fwd: M < 0");
   if (M == 0) return FP_OK;
   FP_REQUIRE(x && w && y && x_geom && y_geom, "fp_igemm_f16_fwd: NULL tensor / geometry");
@@ -237,27 +234,24 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
   FP_REQUIRE(Cin > 0 && Cin % 64 == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of 64", Cin);
   FP_REQUIRE(!residual || r_geom, "fp_igemm_f16_fwd: residual without geometry");
-  FP_REQUIRE((((size_t)x | (size_t)w | (size_t)y | (size_t)residual | (size_t)bias) & 15) == 0,
+  FP_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fp_igemm_f16_fwd: bn_scale and bn_shift go together");
+  FP_REQUIRE(!bn_scale || (flags & FP_IGEMM_ROUND_ACC), "fp_igemm_f16_fwd: BatchNorm needs FP_IGEMM_ROUND_ACC (conv semantics)");
+  FP_REQUIRE((flags & ~(FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC)) == 0, "fp_igemm_f16_fwd: unknown flags 0x%x", flags);
+  FP_REQUIRE((((size_t)x | (size_t)w | (size_t)y | (size_t)residual | (size_t)bias | (size_t)bn_scale | (size_t)bn_shift) & 15) == 0,
              "fp_igemm_f16_fwd: tensors must be 16-byte aligned");
   if (int e = ig_check_geom(x_geom, "input")) return e;
   if (int e = ig_check_geom(y_geom, "output")) return e;
   if (residual) if (int e = ig_check_geom(r_geom, "residual")) return e;
   IgemmParams p;
-  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = bias; p.R = (const _Float16*)residual; p.Y = (_Float16*)y;
-  p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = relu;
+  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+  p.R = (const _Float16*)residual; p.Y = (_Float16*)y;
+  p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = (flags & FP_IGEMM_RELU) ? 1 : 0;
+  p.round_acc = (flags & FP_IGEMM_ROUND_ACC) ? 1 : 0;
   p.in = ig_geom(x_geom); p.out = ig_geom(y_geom); p.res = residual ? ig_geom(r_geom) : ig_geom(y_geom);
-  // FP_CONV3X3=1: stride-1 3x3 convolutions whose input and output share one padded pixel grid go to the
-  // shifted-window kernel (conv3x3.hip: the 9 taps read one LDS-resident input patch instead of 9 operand streams).
-  // Off by default: 1.7-2.3x less operand traffic bought nothing on MI355X (770 vs 763 TFLOP/s nominal at 256
-  // channels, and it computes the border pixels too), which is what ruled the operand stream out as the bound.
-  static int use_sw = -1;
-  if (use_sw < 0) { const char* e = getenv("FP_CONV3X3"); use_sw = e ? atoi(e) : 0; }   // measured: not faster
-  if (use_sw && taps == 9 && p.in.stride == 1 && p.in.off == 0 && p.in.bsplit == 0 && p.in.coff % 8 == 0 &&
-      p.in.Hp * p.in.Wp == (p.in.HoWo / p.in.Wo + 2) * (p.in.Wo + 2) && p.in.Wp == p.in.Wo + 2 && p.in.Wp <= 63 &&
-      M % p.in.HoWo == 0 && M >= 1024 && p.out.HoWo == p.in.HoWo && p.out.Wo == p.in.Wo && p.out.stride == 1 &&
-      (!residual || (p.res.HoWo == p.in.HoWo && p.res.Wo == p.in.Wo && p.res.stride == 1)))
-    return fp_conv3x3s1_launch(p, M / p.in.HoWo, (hipStream_t)stream);
-  // tile selection; FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | pp256x256 | pp256x128 ... forces one (profiling aid)
+  int sel = 0;
+#ifdef FP_PROFILE_BUILD
+  // profiling builds only (make PROFILE=1): FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | pp256x256 | pp256x128 | generic
+  // forces one schedule; the release library has no environment switches on this path
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("FP_IGEMM_TILE");
@@ -266,27 +260,26 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
       if (!strcmp(e, "128x128")) forced = 1;
       else if (!strcmp(e, "256x128")) forced = 2;
       else if (!strcmp(e, "256x256")) forced = 3;
-      else if (!strcmp(e, "128x128k32x3")) forced = 5;
-      else if (!strcmp(e, "128x128k32x4")) forced = 6;
       else if (!strcmp(e, "pp256x256")) forced = 7;
       else if (!strcmp(e, "pp256x128")) forced = 9;
-      else if (!strcmp(e, "ppr256x256")) forced = 10;
+      else if (!strcmp(e, "generic")) forced = 100;   // default selection without the shifted-window kernel
     }
   }
-  int sel = forced;
+  sel = forced;
+#endif
+  // stride-1 3x3 convolutions over one padded pixel grid: the shifted-window kernel (conv_sw.hip) stages every input
+  // pixel once per channel chunk instead of once per tap
+  if (sel == 0 && fp_conv3x3_sw_applicable(p)) return fp_conv3x3_sw_launch(p, (hipStream_t)stream);
+  if (sel == 100) sel = 0;
   // measured at the bench shapes (scripts/bench_igemm.py): the 256x256 ping-pong kernel wins where both M and N are
-  // large (256->256 convs 1026 vs 917 TFLOP/s, QKV projection 767 vs 571), 128x128 (two workgroups per CU) elsewhere
+  // large (QKV projection 767 vs 571 TFLOP/s), 128x128 (two workgroups per CU) elsewhere
   if (sel == 0) sel = ((N % 256) == 0 && (M >= 150000 || N >= 1024)) ? 7 : 1;
   if (sel == 3 && (N % 256) != 0) sel = 2;
-  if ((sel == 7 || sel == 10) && (N % 256) != 0) sel = 9;
+  if (sel == 7 && (N % 256) != 0) sel = 9;
   if (sel >= 7) return fp_igemm_pp_launch(p, sel - 7, (hipStream_t)stream);
-  switch (sel) {
-    case 1: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
-    case 2: return ig_launch<256, 128, 2, 3, 64>(p, (hipStream_t)stream);
-    case 3: return ig_launch<256, 256, 4, 2, 64>(p, (hipStream_t)stream);
-    case 5: return ig_launch<128, 128, 2, 3, 32>(p, (hipStream_t)stream);   // 48 KiB: three workgroups per CU
-    case 6: return ig_launch<128, 128, 2, 4, 32>(p, (hipStream_t)stream);   // 64 KiB: prefetch distance 3
-    default: return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
-  }
+#ifdef FP_PROFILE_BUILD
+  if (sel == 2) return ig_launch<256, 128, 2, 3, 64>(p, (hipStream_t)stream);
+  if (sel == 3) return ig_launch<256, 256, 4, 2, 64>(p, (hipStream_t)stream);
+#endif
+  return ig_launch<128, 128, 2, 2, 64>(p, (hipStream_t)stream);
 }
-

@@ -41,10 +41,14 @@ struct IgemmParams {
   const _Float16* A;
   const _Float16* Wt;   // [N][taps*Cin]
   const float* bias;    // [N] or null
+  const float* bn_scale;   // [N] or null: eval-mode BatchNorm as y = x * scale + shift, applied to the fp16-rounded conv + bias
+  const float* bn_shift;
   const _Float16* R;    // residual or null
   _Float16* Y;
   int M, N, Cin, taps;
   int relu;
+  int round_acc;        // FP_IGEMM_ROUND_ACC: the accumulator is rounded to fp16 BEFORE the bias is added (nn.Conv2d under
+                        // autocast: ATen adds the bias to the fp16 convolution output); 0: one rounding of acc + bias (nn.Linear)
   IgemmGeom in, out, res;
 };
 

@@ -2,9 +2,12 @@
 // tile E[m][n] -> 16-byte coalesced row stores with the residual add and ReLU applied on the way out.
 // Call after a workgroup barrier that retires every read of the staging buffers (the tile reuses them).
 // LDS layout of a kernel that uses it: [0, ig_lds_main) shared by the staging buffers of the main loop and, afterwards,
-// the E tile + its two row-offset tables; then IG_BIAS_LDS bytes of bias (ig_bias_to_lds).
+// the E tile + its two row-offset tables; then IG_BIAS_LDS bytes of per-channel vectors (ig_bias_to_lds).
 #pragma once
 #include "igemm_common.h"
+
+#define IG_VEC_FLOATS 256                       // per-channel epilogue vectors in LDS: bias | BatchNorm scale | BatchNorm shift
+#define IG_BIAS_LDS (3 * IG_VEC_FLOATS * 4)
 
 // FULL: every row of the tile exists (m0 + BM <= M) -- no per-row predicate, so the LDS reads and the stores of the
 // 16 iterations are issued as batches instead of one LDS round trip after the other.
@@ -27,12 +30,7 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
   // bias: staged into LDS at kernel entry (ig_bias_to_lds) -- a global load issued here would be exposed in full, and
   // under the operand stream's load that is several thousand cycles
   typedef float float4_ __attribute__((ext_vector_type(4)));
-  float4_ bv[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      bv[i][g] = *reinterpret_cast<const float4_*>(bias_lds + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5));
+  const bool round_acc = p.round_acc != 0, has_bn = p.bn_scale != nullptr;
   long long* rowY = reinterpret_cast<long long*>(smem + BM * 2 * BN);
   long long* rowR = rowY + BM;
   for (int r = tid; r < BM; r += THREADS) {
@@ -58,12 +56,30 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nl = wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);   // first of 4 consecutive channels (tile-local)
+      // per-channel vectors of these 4 channels (LDS broadcast reads; kept out of registers until here)
+      const float4_ bv = *reinterpret_cast<const float4_*>(bias_lds + nl);
+      float4_ sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (has_bn) {
+        sc = *reinterpret_cast<const float4_*>(bias_lds + IG_VEC_FLOATS + nl);
+        sh = *reinterpret_cast<const float4_*>(bias_lds + 2 * IG_VEC_FLOATS + nl);
+      }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int ml = wm * (32 * TM) + j * 32 + (lane & 31);
         half4 v;
+        if (round_acc) {
+          // the reference's autocast op sequence for conv (+ BatchNorm): every op rounds its result to fp16
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[i][g][e]);
+          for (int e = 0; e < 4; ++e) {
+            float t = (float)(_Float16)acc[i][j][g * 4 + e];
+            t = (float)(_Float16)(t + bv[e]);
+            if (has_bn) t = fmaf(t, sc[e], sh[e]);
+            v[e] = (_Float16)t;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
+        }
         const int chunk = (nl >> 3) ^ (ml & 15);
         *reinterpret_cast<half4*>(E + ml * (2 * BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
       }
@@ -93,15 +109,17 @@ __device__ __forceinline__ void ig_epilogue(const IgemmParams& p, float16_ (&acc
 // Kernel entry, BEFORE the first operand stage is requested: wave 0 sends the tile's bias straight to LDS with one
 // LDS-DMA (1 KiB = 256 floats; reads past the end of the bias vector return 0 through the buffer descriptor's bound).
 // Being the oldest vector-memory operation of the wave it is covered by every later counted vmcnt wait, and it is
-// visible to the workgroup after the first barrier of the main loop.  The LDS area is always 1 KiB (IG_BIAS_LDS).
-#define IG_BIAS_LDS 1024
+// visible to the workgroup after the first barrier of the main loop.  The LDS area is always IG_BIAS_LDS bytes.
+// Three vectors of IG_VEC_FLOATS floats: bias, BatchNorm scale, BatchNorm shift (waves 0, 1, 2 fetch one each).
 __device__ __forceinline__ void ig_bias_to_lds(const IgemmParams& p, int n0, float* bias_lds, int wid, int lane) {
-  if (wid != 0) return;
-  if (p.bias) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)bias_lds, 16, lane * 16, n0 * 4, 0, 0);
-  } else {
+  if (wid > 2) return;
+  const float* src = wid == 0 ? p.bias : (wid == 1 ? p.bn_scale : p.bn_shift);
+  float* dst = bias_lds + wid * IG_VEC_FLOATS;
+  if (src) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, p.N * 4, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, n0 * 4, 0, 0);
+  } else if (wid == 0) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<f4*>(bias_lds + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f4*>(dst + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
   }
 }

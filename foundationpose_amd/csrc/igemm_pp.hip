@@ -205,187 +205,17 @@ static int ig_pp_launch(const IgemmParams& p, hipStream_t stream) {
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_pp<BM, BN, TM, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  FP_SET_MAX_LDS((k_igemm_pp<BM, BN, TM, DBG>), LDS);
   hipLaunchKernelGGL((k_igemm_pp<BM, BN, TM, DBG>), dim3((unsigned)tiles), dim3(512), LDS, stream, p);
   FP_CHECK_LAUNCH("fp_igemm_f16_fwd");
   return FP_OK;
 }
 
 
-// k_igemm_ppr -- ping-pong schedule with REGISTER-staged operands: global -> VGPR (buffer_load_dwordx4) -> LDS
-// (ds_write_b128) instead of LDS-DMA.  Two register sets hold the k-steps h+1 and h+2 while k-step h is multiplied, so a
-// load has two k-step periods to return; the LDS only needs two stages (k-step h+1 is written in the intervals in which
-// k-step h is read, and its buffer was last read for k-step h-1).  Same swizzle: applied on the source address, the
-// LDS image of a piece is lane-linear (conflict-free 16-byte stores).
-typedef unsigned uint4_ __attribute__((ext_vector_type(4)));
-
-template <int BM, int BN, int TM>
-__global__ __launch_bounds__(512, 1) void k_igemm_ppr(IgemmParams p) {
-  constexpr int BK = 32, NW = 8, THREADS = 512;
-  constexpr int NWN = BN / 64;
-  static_assert((BM / (32 * TM)) * NWN == NW, "ping-pong needs exactly 8 waves");
-  constexpr int ROWB = BK * 2, CPK = BK / 8, RPI = 1024 / ROWB, KK = BK / 16;
-  constexpr int A_BYTES = BM * ROWB;
-  constexpr int STAGE_BYTES = A_BYTES + BN * ROWB;
-  constexpr int AI = BM / RPI / NW, WI = BN / RPI / NW;
-  static_assert(AI >= 1 && WI >= 1, "tile too small");
-  auto swz = [](int row) { return (row >> 2) & 3; };
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wid >> 2;
-  const int wm = wid / NWN, wn = wid - wm * NWN;
-  float* bias_lds = reinterpret_cast<float*>(smem + ig_lds_main<BM, BN>(2 * STAGE_BYTES));
-
-  const int tiles_n = p.N / BN;
-  const int nwg = gridDim.x;
-  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int q = nwg >> 3, r8 = nwg & 7;
-  const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
-  const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int Ktot = p.taps * p.Cin;
-  ig_bias_to_lds(p, n0, bias_lds, wid, lane);
-
-  unsigned aoff32[AI], woff32[WI];
-#pragma unroll
-  for (int j = 0; j < AI; ++j) {
-    const int row = wid * (AI * RPI) + j * RPI + lane / CPK;
-    const int c = (lane % CPK) ^ swz(row);
-    int m = m0 + row;
-    m = m < p.M ? m : p.M - 1;
-    aoff32[j] = (unsigned)((ig_row_off(p.in, m) + c * 8) * 2);
-  }
-#pragma unroll
-  for (int j = 0; j < WI; ++j) {
-    const int row = wid * (WI * RPI) + j * RPI + lane / CPK;
-    const int c = (lane % CPK) ^ swz(row);
-    woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
-  }
-  const int nk = p.taps * (p.Cin / BK);            // even: Cin is a multiple of 64
-  int st_ci0 = 0, st_kx = 0, st_ky = 0, st_k = 0;
-  const int inWp = p.in.Wp, inCs = p.in.cstride, Cin = p.Cin;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Wt), 0, 0x7FFFFFFF, 0x00020000);
-
-  uint4_ ra[2][AI], rw[2][WI];                      // two register sets (k-steps in flight)
-  auto gload = [&](uint4_ (&da)[AI], uint4_ (&dw)[WI]) {   // request the next k-step (running state) into one set
-    const int asoff = (((st_ky * inWp + st_kx) * inCs) + st_ci0) * 2;
-    const int wsoff = st_k * (BK * 2);
-#pragma unroll
-    for (int j = 0; j < AI; ++j) da[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff32[j], asoff, 0);
-#pragma unroll
-    for (int j = 0; j < WI; ++j) dw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)woff32[j], wsoff, 0);
-    // past the last k-step the state stays put: the loop issues loads unconditionally (re-reading the last k-step into
-    // a set nobody consumes), which keeps the main loop free of branches around loads, so hipcc's vmcnt counts are exact
-    if (st_k + 1 < nk) {
-      ++st_k;
-      st_ci0 += BK;
-      if (st_ci0 == Cin) { st_ci0 = 0; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
-    }
-  };
-  auto lstore = [&](int buf, uint4_ (&da)[AI], uint4_ (&dw)[WI]) {
-    unsigned char* sa = smem + buf * STAGE_BYTES + wid * (AI * 1024) + lane * 16;
-    unsigned char* sw = smem + buf * STAGE_BYTES + A_BYTES + wid * (WI * 1024) + lane * 16;
-#pragma unroll
-    for (int j = 0; j < AI; ++j) *reinterpret_cast<uint4_*>(sa + j * 1024) = da[j];
-#pragma unroll
-    for (int j = 0; j < WI; ++j) *reinterpret_cast<uint4_*>(sw + j * 1024) = dw[j];
-  };
-
-  float16_ acc[2][TM];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int frow = lane & 31, fhalf = lane >> 5;
-  int a_off[TM][KK], w_off[2][KK];
-#pragma unroll
-  for (int t = 0; t < TM; ++t) {
-    const int r = wm * (32 * TM) + t * 32 + frow;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) a_off[t][kk] = r * ROWB + (((2 * kk + fhalf) ^ swz(r)) << 4);
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int r = wn * 64 + t * 32 + frow;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) w_off[t][kk] = A_BYTES + r * ROWB + (((2 * kk + fhalf) ^ swz(r)) << 4);
-  }
-
-  // ---- prologue: k-step 0 in LDS stage 0; k-step 1 in set 1, k-step 2 in set 0 (in flight)
-  gload(ra[0], rw[0]);
-  lstore(0, ra[0], rw[0]);
-  gload(ra[1], rw[1]);
-  gload(ra[0], rw[0]);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp) __builtin_amdgcn_s_barrier();
-
-  half8 fa[KK][TM], fw[KK][2];
-  // one k-step: `cur` = LDS stage of k-step ks, (na, nw) = the register set that holds k-step ks+1
-  auto kstep = [&](int cur, uint4_ (&na)[AI], uint4_ (&nw)[WI]) {
-    const unsigned char* sb = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-      for (int t = 0; t < TM; ++t) fa[kk][t] = *reinterpret_cast<const half8*>(sb + a_off[t][kk]);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) fw[kk][t] = *reinterpret_cast<const half8*>(sb + w_off[t][kk]);
-    }
-    lstore(cur ^ 1, na, nw);                       // hipcc inserts the counted vmcnt for this set (the younger set stays in flight)
-    gload(na, nw);                                 // the set is free again: request k-step ks+3
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (int ks = 0; ks < nk; ks += 2) {
-    kstep(0, ra[1], rw[1]);
-    kstep(1, ra[0], rw[0]);
-  }
-  if (!grp) __builtin_amdgcn_s_barrier();
-  __syncthreads();
-  ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
-}
-
-template <int BM, int BN, int TM>
-static int ig_ppr_launch(const IgemmParams& p, hipStream_t stream) {
-  constexpr int LDS = ig_lds_main<BM, BN>(2 * (BM + BN) * 32 * 2) + IG_BIAS_LDS;
-  static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
-  FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm_ppr<BM, BN, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((k_igemm_ppr<BM, BN, TM>), dim3((unsigned)tiles), dim3(512), LDS, stream, p);
-  FP_CHECK_LAUNCH("fp_igemm_f16_fwd");
-  return FP_OK;
-}
-
-// variant: 0 = 256x256 (N % 256 == 0), 3 = 256x256 register-staged, otherwise 256x128
+// variant: 0 = 256x256 (N % 256 == 0), otherwise 256x128.  The resource-isolation builds (DBG != 0: results wrong by
+// construction) exist only in a profiling build (make PROFILE=1), selected there by FP_IGEMM_DBG.
 int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream) {
+#ifdef FP_PROFILE_BUILD
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("FP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
   if (variant == 0 && dbg) {
@@ -396,9 +226,7 @@ int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream) {
       default: return ig_pp_launch<256, 256, 4, 9>(p, stream);
     }
   }
-  if (variant == 3) return ig_ppr_launch<256, 256, 4>(p, stream);
-  switch (variant) {
-    case 0: return ig_pp_launch<256, 256, 4, 0>(p, stream);
-    default: return ig_pp_launch<256, 128, 2, 0>(p, stream);
-  }
+#endif
+  if (variant == 0) return ig_pp_launch<256, 256, 4, 0>(p, stream);
+  return ig_pp_launch<256, 128, 2, 0>(p, stream);
 }

@@ -540,11 +540,7 @@ extern "C" int fp_render_crops(const fp_mesh* mesh, const float* poses, const fl
   hipLaunchKernelGGL(k_bin, dim3(fp_cdiv(mesh->T, 256), N), dim3(256), 0, st, *mesh, oh, ow, L.nstrips, ws);
   FP_CHECK_LAUNCH("fp_render_crops(bin)");
   const size_t lds = (size_t)FP_STRIP_ROWS * ow * sizeof(unsigned long long) + 16 + FP_BIG_MAX * sizeof(BigTri);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_raster), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  FP_SET_MAX_LDS(k_raster, 160 * 1024);
   hipLaunchKernelGGL(k_raster, dim3(L.nstrips, N), dim3(FP_RASTER_THREADS), lds, st, *mesh, poses, bbox2d, K, H, W, oh, ow,
                      L.nstrips, w_ambient, w_diffuse, inv_r, xyz_thr, flags, out, ws);
   FP_CHECK_LAUNCH("fp_render_crops");

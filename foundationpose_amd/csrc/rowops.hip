@@ -1,14 +1,24 @@
-// Row-wise ops of the transformer heads (refine_network.py:56-70 nn.TransformerEncoderLayer post-norm LayerNorms and
-// the `.mean(dim=1)` over the 400 tokens, refine_network.py:90-91 / score_network.py:74), gfx950.  Pure HBM streams:
-//   fp_layernorm_f16_fwd : y = LN(x) * gamma + beta, one wave per 512-wide row, 16 bytes per lane in and out, fp32
-//                          statistics (two-pass in registers: mean, then centred variance), wave reduction by DPP/shuffle
-//   fp_colmean_f16_fwd   : out[g] = mean over the rows of group g of (LN(x) or x) -- the token mean fused with the last
-//                          LayerNorm, so the normalised (N,400,512) tensor is never written; one 1024-thread
-//                          workgroup per group, fixed summation order (deterministic)
+// Row-wise ops of the transformer heads (refine_network.py:56-70 nn.TransformerEncoderLayer, post-norm; the
+// `.mean(dim=1)` over the 400 tokens, refine_network.py:90-91 / score_network.py:74; PositionalEmbedding,
+// network_modules.py:133-137; the N-row Linear layers that follow the token mean), gfx950.  Pure HBM streams.
+//
+// Arithmetic policy = the reference's autocast(fp16) op sequence (oracle/nets_amp.py): the residual stream of the
+// encoder layer and both LayerNorms are fp32 (their inputs are fp32: fp16 tokens + the fp32 positional table), every
+// Linear consumes the fp16 rounding of that stream and produces fp16.  So the stream exists twice in HBM: fp32 for the
+// next residual add, fp16 as the next GEMM operand.
+//   fp_add_pe_f16_fwd        : x16 = fp16(fp32(tok16) + pe)                       -- the in_proj operand
+//   fp_layernorm_res_fwd     : z = resid + fp32(branch16); y = LN(z)*gamma + beta -> y32 and y16;  resid = x32 or
+//                              fp32(tok16) + pe (the layer input is never materialised in fp32)
+//   fp_colmean_f16_fwd       : out[g] = mean over the rows of group g of LN(resid32 + fp32(x16)) or of x16 -- the token
+//                              mean fused with the last LayerNorm, so the normalised (N,400,512) tensor is never written
+//   fp_rows_linear_fwd       : y = x32 @ w16^T + b for a few hundred rows (the heads after the token mean)
+// One wave per 512-wide row, 8 elements per lane, fp32 statistics (two-pass in registers: mean, then centred variance),
+// fixed summation order (deterministic).
 #include <hip/hip_fp16.h>
 #include "fp_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4_ __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -16,11 +26,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// row of 512 halves held as 8 per lane -> normalised values (fp32) in f[8]
-__device__ __forceinline__ void ln_row(const half8 x, float eps, float f[8]) {
+__device__ __forceinline__ void load8f(const float* p, float f[8]) {
+  const float4_ a = *reinterpret_cast<const float4_*>(p), b = *reinterpret_cast<const float4_*>(p + 4);
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
+__device__ __forceinline__ void store8f(float* p, const float f[8]) {
+  *reinterpret_cast<float4_*>(p) = float4_{f[0], f[1], f[2], f[3]};
+  *reinterpret_cast<float4_*>(p + 4) = float4_{f[4], f[5], f[6], f[7]};
+}
+
+// f[8] (one row of 512 spread over the wave) -> (f - mean) * rstd, in place
+__device__ __forceinline__ void ln_row(float eps, float f[8]) {
   float s = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { f[e] = (float)x[e]; s += f[e]; }
+  for (int e = 0; e < 8; ++e) s += f[e];
   const float mean = wave_sum(s) * (1.0f / 512.0f);
   float q = 0.f;
 #pragma unroll
@@ -30,38 +50,78 @@ __device__ __forceinline__ void ln_row(const half8 x, float eps, float f[8]) {
   for (int e = 0; e < 8; ++e) f[e] *= rstd;
 }
 
-__global__ __launch_bounds__(256) void k_layernorm512(const _Float16* __restrict__ X, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float eps, _Float16* __restrict__ Y,
-                                                      int M) {
+// residual-stream value of row `row`, elements [8 lane, 8 lane + 8): x32 if given, else fp32(tok16) + pe[row % S]
+__device__ __forceinline__ void resid_row(const float* x32, const _Float16* tok16, const float* pe, int S, size_t row, int lane,
+                                          float f[8]) {
+  if (x32) {
+    load8f(x32 + row * 512 + lane * 8, f);
+  } else {
+    const half8 t = *reinterpret_cast<const half8*>(tok16 + row * 512 + lane * 8);
+    float pv[8];
+    load8f(pe + (size_t)(row % (size_t)S) * 512 + lane * 8, pv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)t[e] + pv[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_add_pe512(const _Float16* __restrict__ tok, const float* __restrict__ pe,
+                                                   _Float16* __restrict__ out, int M, int S) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const half8 x = *reinterpret_cast<const half8*>(X + (size_t)row * 512 + lane * 8);
   float f[8];
-  ln_row(x, eps, f);
+  resid_row(nullptr, tok, pe, S, (size_t)row, lane, f);
   half8 y;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) y[e] = (_Float16)fmaf(f[e], gamma[lane * 8 + e], beta[lane * 8 + e]);
-  *reinterpret_cast<half8*>(Y + (size_t)row * 512 + lane * 8) = y;
+  for (int e = 0; e < 8; ++e) y[e] = (_Float16)f[e];
+  *reinterpret_cast<half8*>(out + (size_t)row * 512 + lane * 8) = y;
+}
+
+__global__ __launch_bounds__(256) void k_layernorm_res512(const float* __restrict__ x32, const _Float16* __restrict__ tok16,
+                                                          const float* __restrict__ pe, int S,
+                                                          const _Float16* __restrict__ branch, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float* __restrict__ y32,
+                                                          _Float16* __restrict__ y16, int M) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float f[8], gm[8], bt[8];
+  resid_row(x32, tok16, pe, S, (size_t)row, lane, f);
+  const half8 b = *reinterpret_cast<const half8*>(branch + (size_t)row * 512 + lane * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] += (float)b[e];
+  ln_row(eps, f);
+  load8f(gamma + lane * 8, gm);
+  load8f(beta + lane * 8, bt);
+  half8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { f[e] = fmaf(f[e], gm[e], bt[e]); h[e] = (_Float16)f[e]; }
+  if (y32) store8f(y32 + (size_t)row * 512 + lane * 8, f);
+  if (y16) *reinterpret_cast<half8*>(y16 + (size_t)row * 512 + lane * 8) = h;
 }
 
 template <bool LN>
-__global__ __launch_bounds__(1024) void k_colmean512(const _Float16* __restrict__ X, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps, float* __restrict__ out,
-                                                     int rows_per_group) {
+__global__ __launch_bounds__(1024) void k_colmean512(const _Float16* __restrict__ X, const float* __restrict__ R32,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                     float* __restrict__ out, int rows_per_group) {
   __shared__ float part[16][512];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = blockIdx.x;
-  const _Float16* Xg = X + (size_t)g * rows_per_group * 512;
+  const size_t base = (size_t)g * rows_per_group * 512;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int r = wid; r < rows_per_group; r += 16) {
-    const half8 x = *reinterpret_cast<const half8*>(Xg + (size_t)r * 512 + lane * 8);
+    const half8 x = *reinterpret_cast<const half8*>(X + base + (size_t)r * 512 + lane * 8);
     float f[8];
-    if (LN) {
-      ln_row(x, eps, f);
-    } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (float)x[e];
+    for (int e = 0; e < 8; ++e) f[e] = (float)x[e];
+    if (LN) {
+      if (R32) {
+        float rr[8];
+        load8f(R32 + base + (size_t)r * 512 + lane * 8, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+      }
+      ln_row(eps, f);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += f[e];
@@ -80,31 +140,116 @@ __global__ __launch_bounds__(1024) void k_colmean512(const _Float16* __restrict_
   }
 }
 
-extern "C" int fp_layernorm_f16_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, int M,
-                                    int D, void* stream) {
-  FP_REQUIRE(M >= 0, "fp_layernorm_f16_fwd: M < 0");
+// y[m][n] = sum_k x[m][k] * w[n][k] + b[n]: 4 rows of x per workgroup (fp32, in LDS), wave w takes outputs n = w, w+4, ...;
+// a lane owns 8 consecutive k of every 512-wide k block, so a weight row is read as whole 1 KiB lines.
+#define RL_ROWS 4
+template <bool X16, bool Y16>
+__global__ __launch_bounds__(256) void k_rows_linear(const void* __restrict__ Xv, const _Float16* __restrict__ Wt,
+                                                     const float* __restrict__ bias, void* __restrict__ Yv, int M, int K, int N,
+                                                     int round_f16) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rl[];
+  float* xs = reinterpret_cast<float*>(smem_rl);          // [RL_ROWS][K]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * RL_ROWS;
+  for (int i = threadIdx.x; i < RL_ROWS * K; i += 256) {
+    const int r = i / K, k = i - r * K;
+    float v = 0.f;
+    if (m0 + r < M)
+      v = X16 ? (float)reinterpret_cast<const _Float16*>(Xv)[(size_t)(m0 + r) * K + k]
+              : reinterpret_cast<const float*>(Xv)[(size_t)(m0 + r) * K + k];
+    xs[i] = v;
+  }
+  __syncthreads();
+  for (int n = wid; n < N; n += 4) {
+    float acc[RL_ROWS] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 512) {
+      const int k = k0 + lane * 8;
+      if (k < K) {
+        const half8 w = *reinterpret_cast<const half8*>(Wt + (size_t)n * K + k);
+#pragma unroll
+        for (int r = 0; r < RL_ROWS; ++r) {
+          float xv[8];
+          load8f(xs + r * K + k, xv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[r] = fmaf(xv[e], (float)w[e], acc[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RL_ROWS; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane < RL_ROWS && m0 + lane < M) {
+      float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+      v += bias ? bias[n] : 0.f;
+      if (Y16) reinterpret_cast<_Float16*>(Yv)[(size_t)(m0 + lane) * N + n] = (_Float16)v;
+      else reinterpret_cast<float*>(Yv)[(size_t)(m0 + lane) * N + n] = round_f16 ? (float)(_Float16)v : v;
+    }
+  }
+}
+
+extern "C" int fp_add_pe_f16_fwd(const void* tok, const float* pe, void* out, int M, int S, int D, void* stream) {
+  FP_REQUIRE(M >= 0, "fp_add_pe_f16_fwd: M < 0");
   if (M == 0) return FP_OK;
-  FP_REQUIRE(x && gamma && beta && y, "fp_layernorm_f16_fwd: NULL tensor");
-  FP_REQUIRE(D == 512, "fp_layernorm_f16_fwd: D=%d unsupported (d_model of both networks is 512)", D);
-  hipLaunchKernelGGL(k_layernorm512, dim3(fp_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, gamma, beta,
-                     eps, (_Float16*)y, M);
-  FP_CHECK_LAUNCH("fp_layernorm_f16_fwd");
+  FP_REQUIRE(tok && pe && out && S > 0, "fp_add_pe_f16_fwd: bad arguments");
+  FP_REQUIRE(D == 512, "fp_add_pe_f16_fwd: D=%d unsupported (d_model of both networks is 512)", D);
+  hipLaunchKernelGGL(k_add_pe512, dim3(fp_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)tok, pe,
+                     (_Float16*)out, M, S);
+  FP_CHECK_LAUNCH("fp_add_pe_f16_fwd");
   return FP_OK;
 }
 
-extern "C" int fp_colmean_f16_fwd(const void* x, const float* gamma, const float* beta, float eps, float* out, int groups,
-                                  int rows_per_group, int D, void* stream) {
+extern "C" int fp_layernorm_res_fwd(const float* x32, const void* tok16, const float* pe, int S, const void* branch16,
+                                    const float* gamma, const float* beta, float eps, float* y32, void* y16, int M, int D,
+                                    void* stream) {
+  FP_REQUIRE(M >= 0, "fp_layernorm_res_fwd: M < 0");
+  if (M == 0) return FP_OK;
+  FP_REQUIRE(branch16 && gamma && beta && (y32 || y16), "fp_layernorm_res_fwd: NULL tensor");
+  FP_REQUIRE((x32 != nullptr) != (tok16 != nullptr), "fp_layernorm_res_fwd: give the residual as x32 OR as tok16 (+ pe)");
+  FP_REQUIRE(x32 || (pe && S > 0), "fp_layernorm_res_fwd: tok16 needs the positional table and its period");
+  FP_REQUIRE(D == 512, "fp_layernorm_res_fwd: D=%d unsupported (d_model of both networks is 512)", D);
+  hipLaunchKernelGGL(k_layernorm_res512, dim3(fp_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x32, (const _Float16*)tok16,
+                     pe, S, (const _Float16*)branch16, gamma, beta, eps, y32, (_Float16*)y16, M);
+  FP_CHECK_LAUNCH("fp_layernorm_res_fwd");
+  return FP_OK;
+}
+
+extern "C" int fp_colmean_f16_fwd(const void* x, const float* resid32, const float* gamma, const float* beta, float eps,
+                                  float* out, int groups, int rows_per_group, int D, void* stream) {
   FP_REQUIRE(groups >= 0, "fp_colmean_f16_fwd: groups < 0");
   if (groups == 0) return FP_OK;
   FP_REQUIRE(x && out && rows_per_group > 0, "fp_colmean_f16_fwd: bad arguments");
   FP_REQUIRE(D == 512, "fp_colmean_f16_fwd: D=%d unsupported (d_model of both networks is 512)", D);
   FP_REQUIRE((gamma == nullptr) == (beta == nullptr), "fp_colmean_f16_fwd: gamma and beta go together");
+  FP_REQUIRE(gamma || !resid32, "fp_colmean_f16_fwd: a residual only makes sense with the LayerNorm");
   if (gamma)
-    hipLaunchKernelGGL(k_colmean512<true>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)x, gamma, beta,
-                       eps, out, rows_per_group);
+    hipLaunchKernelGGL(k_colmean512<true>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)x, resid32, gamma,
+                       beta, eps, out, rows_per_group);
   else
-    hipLaunchKernelGGL(k_colmean512<false>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)x, gamma, beta,
-                       eps, out, rows_per_group);
+    hipLaunchKernelGGL(k_colmean512<false>, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const _Float16*)x, resid32, gamma,
+                       beta, eps, out, rows_per_group);
   FP_CHECK_LAUNCH("fp_colmean_f16_fwd");
+  return FP_OK;
+}
+
+extern "C" int fp_rows_linear_fwd(const void* x, const void* w, const float* bias, void* y, int M, int K, int N,
+                                  int flags, void* stream) {
+  FP_REQUIRE(M >= 0 && N >= 0, "fp_rows_linear_fwd: negative size");
+  if (M == 0 || N == 0) return FP_OK;
+  FP_REQUIRE(x && w && y, "fp_rows_linear_fwd: NULL tensor");
+  FP_REQUIRE(K > 0 && K % 8 == 0 && K <= 2048, "fp_rows_linear_fwd: K=%d must be a multiple of 8 (<= 2048)", K);
+  FP_REQUIRE((((size_t)x | (size_t)w) & 15) == 0, "fp_rows_linear_fwd: tensors must be 16-byte aligned");
+  FP_REQUIRE((flags & ~(FP_ROWS_ROUND_F16 | FP_ROWS_X_F16 | FP_ROWS_Y_F16)) == 0, "fp_rows_linear_fwd: unknown flags 0x%x", flags);
+  const dim3 grid(fp_cdiv(M, RL_ROWS)), block(256);
+  const size_t lds = (size_t)RL_ROWS * K * sizeof(float);
+  const int rnd = (flags & FP_ROWS_ROUND_F16) ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  const _Float16* wt = (const _Float16*)w;
+  if (flags & FP_ROWS_X_F16) {
+    if (flags & FP_ROWS_Y_F16) hipLaunchKernelGGL((k_rows_linear<true, true>), grid, block, lds, st, x, wt, bias, y, M, K, N, rnd);
+    else hipLaunchKernelGGL((k_rows_linear<true, false>), grid, block, lds, st, x, wt, bias, y, M, K, N, rnd);
+  } else {
+    if (flags & FP_ROWS_Y_F16) hipLaunchKernelGGL((k_rows_linear<false, true>), grid, block, lds, st, x, wt, bias, y, M, K, N, rnd);
+    else hipLaunchKernelGGL((k_rows_linear<false, false>), grid, block, lds, st, x, wt, bias, y, M, K, N, rnd);
+  }
+  FP_CHECK_LAUNCH("fp_rows_linear_fwd");
   return FP_OK;
 }

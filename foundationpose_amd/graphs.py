@@ -30,6 +30,11 @@ class GraphedTracker:
         self.rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=self.dev)
         self.depth = torch.zeros((H, W), dtype=torch.float32, device=self.dev)
         self.poses_in = torch.eye(4, device=self.dev).repeat(self.N, 1, 1).contiguous()
+        # everything the captured kernels address by raw pointer and that is not allocated inside the capture belongs to
+        # the tracker: the rasteriser scratch here, the encoder's activation buffers by key in the plan (never dropped)
+        oh, ow = int(refiner.cfg["input_resize"][0]), int(refiner.cfg["input_resize"][1])
+        self.workspace = torch.empty(max(16, ops.workspace_bytes(self.N, self.handle.V, self.handle.T, oh, ow)),
+                                     dtype=torch.uint8, device=self.dev)
         self.poses_out = None
         self.graph = None
 
@@ -37,7 +42,7 @@ class GraphedTracker:
         d = ops.bilateral_filter_depth(ops.erode_depth(self.depth, radius=2), radius=2)
         xyz = ops.depth_to_xyz(d, self.K, zfar=float("inf"), f64_internal=False)     # depth2xyzmap_batch variant
         poses, _, _ = self.refiner.refine_device(self.rgb, xyz, self.poses_in, self.K, self.H, self.W, self.handle,
-                                                 self.diameter, self.R)
+                                                 self.diameter, self.R, workspace=self.workspace)
         return poses
 
     @torch.inference_mode()

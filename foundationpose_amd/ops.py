@@ -14,8 +14,16 @@ ROT_AXIS_ANGLE = 0
 ROT_6D = 1
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t=None):
+    """HIP stream the launch goes to: PyTorch's current stream of the tensor's device.  A tensor on another device than
+    the thread's current one is refused (launches go to the current device): use torch.cuda.set_device / torch.cuda.device."""
+    if t is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = t.device
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        raise _lib.FpAmdError(f"tensor on {dev} but the current device is cuda:{torch.cuda.current_device()}: wrap the call in "
+                              f"`with torch.cuda.device({dev.index}):` (kernels launch on the current device)")
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _dev(t, dtype, name):
@@ -81,7 +89,7 @@ def erode_depth(depth, radius=2, depth_diff_thres=0.001, ratio_thres=0.8, zfar=1
     out = torch.empty_like(d)
     H, W = d.shape
     _lib.check(_lib.lib().fp_depth_erode(_ptr(d), _ptr(out), H, W, int(radius), depth_diff_thres, ratio_thres, zfar,
-                                         _stream()), "fp_depth_erode")
+                                         _stream(d)), "fp_depth_erode")
     return out
 
 
@@ -89,7 +97,7 @@ def bilateral_filter_depth(depth, radius=2, zfar=100.0, sigmaD=2.0, sigmaR=10000
     d = _dev(depth, torch.float32, "depth")
     out = torch.empty_like(d)
     H, W = d.shape
-    _lib.check(_lib.lib().fp_depth_bilateral(_ptr(d), _ptr(out), H, W, int(radius), zfar, sigmaD, sigmaR, _stream()),
+    _lib.check(_lib.lib().fp_depth_bilateral(_ptr(d), _ptr(out), H, W, int(radius), zfar, sigmaD, sigmaR, _stream(d)),
                "fp_depth_bilateral")
     return out
 
@@ -100,7 +108,7 @@ def depth_to_xyz(depth, K, zfar=float("inf"), f64_internal=False):
     out = torch.empty((H, W, 3), dtype=torch.float32, device=d.device)
     Kd = _hostK64(K)
     _lib.check(_lib.lib().fp_depth_to_xyz(_ptr(d), Kd.ctypes.data_as(C.c_void_p), float(zfar), int(bool(f64_internal)),
-                                          _ptr(out), H, W, _stream()), "fp_depth_to_xyz")
+                                          _ptr(out), H, W, _stream(d)), "fp_depth_to_xyz")
     return out
 
 
@@ -113,11 +121,15 @@ def crop_windows(poses, K, mesh_diameter, crop_ratio, out_size=(160, 160)):
     Kd = _hostK64(K)
     _lib.check(_lib.lib().fp_crop_windows(_ptr(P), Kd.ctypes.data_as(C.c_void_p), float(mesh_diameter),
                                           float(crop_ratio), int(out_size[0]), int(out_size[1]), N, _ptr(tf), _ptr(bb),
-                                          _stream()), "fp_crop_windows")
+                                          _stream(P)), "fp_crop_windows")
     return tf, bb
 
 
 _WS = {}
+
+
+def workspace_bytes(N, V, T, oh=160, ow=160):
+    return int(_lib.lib().fp_workspace_bytes(int(N), int(V), int(T), int(oh), int(ow)))
 
 
 def _workspace(nbytes, device):
@@ -133,8 +145,10 @@ def _workspace(nbytes, device):
 
 def render_crops(mesh, poses, bbox2d, K, H, W, out_hw=(160, 160), mesh_diameter=1.0, xyz_thr=0.001,
                  normalize_xyz=True, out_f16=False, w_ambient=0.8, w_diffuse=0.5,
-                 want=("A",), A_out=None):
-    """Fused render of N hypotheses (see fp_render_crops).  Returns dict of requested outputs."""
+                 want=("A",), A_out=None, workspace=None):
+    """Fused render of N hypotheses (see fp_render_crops).  Returns dict of requested outputs.  workspace: caller-owned
+    uint8 scratch of at least workspace_bytes(...) bytes (a captured hipGraph must own its scratch); default: a
+    per-device scratch that grows on demand."""
     P = _dev(poses, torch.float32, "poses")
     N = int(P.shape[0])
     bb = _dev(bbox2d, torch.float32, "bbox2d")
@@ -160,13 +174,19 @@ def render_crops(mesh, poses, bbox2d, K, H, W, out_hw=(160, 160), mesh_diameter=
     zbuf = alloc("zbuf", (N, oh, ow), torch.int32)  # u32 payload, viewed as int32 by torch
     tri = alloc("tri_id", (N, oh, ow), torch.int32)
     L = _lib.lib()
-    ws = _workspace(L.fp_workspace_bytes(N, mesh.V, mesh.T, oh, ow), dev)
+    need = L.fp_workspace_bytes(N, mesh.V, mesh.T, oh, ow)
+    if workspace is not None:
+        ws = _dev(workspace, torch.uint8, "workspace")
+        if ws.numel() < need:
+            raise _lib.FpAmdError(f"render_crops: workspace has {ws.numel()} bytes, {need} needed")
+    else:
+        ws = _workspace(need, dev)
     K9 = _hostK32(K)
     flags = (FLAG_NORMALIZE_XYZ if normalize_xyz else 0) | (FLAG_OUT_F16 if (A is not None and A.dtype == torch.float16) else 0)
     st = L.fp_render_crops(mesh.handle, _ptr(P), _ptr(bb), K9.ctypes.data_as(C.c_void_p), int(H), int(W), N, oh, ow,
                            w_ambient, w_diffuse, float(np.float32(mesh_diameter)), xyz_thr, flags, _ptr(A), _ptr(color),
                            _ptr(depth), _ptr(xyz), _ptr(normal), _ptr(zbuf), _ptr(tri), _ptr(ws),
-                           0 if ws is None else ws.numel(), _stream())
+                           0 if ws is None else ws.numel(), _stream(P))
     _lib.check(st, "fp_render_crops")
     return outs
 
@@ -186,13 +206,13 @@ def warp_crops(rgb, xyz_map, depth, tf_to_crops, K, poses, mesh_diameter, mode, 
     flags = (FLAG_NORMALIZE_XYZ if normalize_xyz else 0) | (FLAG_OUT_F16 if B.dtype == torch.float16 else 0)
     K9 = _hostK32(K)
     st = _lib.lib().fp_warp_crops(_ptr(rgbf), _ptr(xm), _ptr(dp), _ptr(tf), K9.ctypes.data_as(C.c_void_p), _ptr(P),
-                                  float(np.float32(mesh_diameter)), flags, int(mode), H, W, N, oh, ow, _ptr(B), _stream())
+                                  float(np.float32(mesh_diameter)), flags, int(mode), H, W, N, oh, ow, _ptr(B), _stream(P))
     _lib.check(st, "fp_warp_crops")
     return B
 
 
 def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, trans_normalizer=(1.0, 1.0, 1.0),
-                rot_normalizer=1.0, mesh_diameter=1.0, out=None):
+                rot_normalizer=1.0, mesh_diameter=1.0, out=None, trans_delta_out=None, rot_delta_out=None):
     tr = _dev(trans, torch.float32, "trans")
     ro = _dev(rot, torch.float32, "rot")
     P = _dev(poses, torch.float32, "poses")
@@ -207,48 +227,29 @@ def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, tra
     O = out if out is not None else torch.empty_like(P)
     st = _lib.lib().fp_pose_update(_ptr(tr), _ptr(ro), _ptr(P), rr, int(bool(normalize_xyz)),
                                    tn.ctypes.data_as(C.c_void_p), float(rot_normalizer), float(np.float32(mesh_diameter)),
-                                   N, _ptr(O), _stream())
+                                   N, _ptr(O), _ptr(_dev(trans_delta_out, torch.float32, "trans_delta_out")),
+                                   _ptr(_dev(rot_delta_out, torch.float32, "rot_delta_out")), _stream(P))
     _lib.check(st, "fp_pose_update")
     return O
 
 
-def conv7x7s2_bn_relu(x, w_flat, scale, shift, channels_last=False, out_padded=None):
-    """x (B,6,H,W) f16 NCHW -> (B,64,H/2,W/2) f16 (logical NCHW; channels_last memory format if asked).
-    out_padded: a zero-bordered (B, H/2+2, W/2+2, 64) NHWC buffer to write the interior of (returned as is)."""
+def conv7x7s2_bn_relu(x, w_flat, bias, scale, shift, out, pad):
+    """x (B,6,H,W) f16 NCHW -> interior of `out` (B, H/2 + 2 pad, W/2 + 2 pad, 64) f16 NHWC (border untouched), following
+    the autocast op sequence conv -> fp16, + bias -> fp16, eval BatchNorm -> fp16, ReLU (fp_conv7x7s2_bn_relu_fwd).
+    bias (fp16-representable values), scale, shift: (64) f32 or None."""
     x = _dev(x, torch.float16, "x")
     w = _dev(w_flat, torch.float16, "w")
-    sc = _dev(scale, torch.float32, "scale")
-    sh = _dev(shift, torch.float32, "shift")
+    y = _dev(out, torch.float16, "out")
     Bn, Cin, H, W = x.shape
     if Cin != 6:
         raise _lib.FpAmdError("conv7x7s2_bn_relu: C_in must be 6")
-    mode = 1 if channels_last else 0
-    if out_padded is not None:
-        y = _dev(out_padded, torch.float16, "out_padded")
-        if tuple(y.shape) != (Bn, H // 2 + 2, W // 2 + 2, 64):
-            raise _lib.FpAmdError(f"conv7x7s2_bn_relu: out_padded has shape {tuple(y.shape)}")
-        mode = 2
-    elif channels_last:
-        y = torch.empty((Bn, 64, H // 2, W // 2), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
-    else:
-        y = torch.empty((Bn, 64, H // 2, W // 2), dtype=torch.float16, device=x.device)
-    st = _lib.lib().fp_conv7x7s2_bn_relu_fwd(_ptr(x), _ptr(w), _ptr(sc), _ptr(sh), _ptr(y), int(Bn), int(H), int(W),
-                                             mode, _stream())
+    if tuple(y.shape) != (Bn, H // 2 + 2 * pad, W // 2 + 2 * pad, 64):
+        raise _lib.FpAmdError(f"conv7x7s2_bn_relu: out has shape {tuple(y.shape)}")
+    st = _lib.lib().fp_conv7x7s2_bn_relu_fwd(_ptr(x), _ptr(w), _ptr(_dev(bias, torch.float32, "bias")),
+                                             _ptr(_dev(scale, torch.float32, "scale")), _ptr(_dev(shift, torch.float32, "shift")),
+                                             _ptr(y), int(Bn), int(H), int(W), int(pad), _stream(x))
     _lib.check(st, "fp_conv7x7s2_bn_relu_fwd")
     return y
-
-
-def linear_f16(x, w, bias=None, relu=False):
-    """y = x @ w.T + bias ; x (...,K) f16, w (Nout,K) f16, bias (Nout) f32."""
-    x2 = _dev(x.reshape(-1, x.shape[-1]), torch.float16, "x")
-    w = _dev(w, torch.float16, "w")
-    b = _dev(bias, torch.float32, "bias")
-    M, K = x2.shape
-    Nout = int(w.shape[0])
-    y = torch.empty((M, Nout), dtype=torch.float16, device=x.device)
-    st = _lib.lib().fp_linear_f16_fwd(_ptr(x2), _ptr(w), _ptr(b), _ptr(y), int(M), int(K), Nout, int(bool(relu)), _stream())
-    _lib.check(st, "fp_linear_f16_fwd")
-    return y.reshape(*x.shape[:-1], Nout)
 
 
 class IgemmGeom(C.Structure):
@@ -269,54 +270,100 @@ class IgemmGeom(C.Structure):
                          C_, coff, bsplit, cgroup)
 
 
-def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None):
-    """y = act(implicit_gemm(x, w) + bias (+ residual)) -- see fp_igemm_f16_fwd.  All tensors fp16 device buffers
-    owned by the caller (y is written in place and returned)."""
+IGEMM_RELU = 1
+IGEMM_ROUND_ACC = 2
+
+
+def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None, bn_scale=None,
+              bn_shift=None, conv_rounding=False):
+    """y = act(f16(epilogue(implicit_gemm(x, w))) (+ residual)) -- see fp_igemm_f16_fwd.  conv_rounding: nn.Conv2d under
+    autocast (accumulator rounded to fp16 before the bias add, optional BatchNorm as scale/shift with its own rounding);
+    otherwise nn.Linear (one rounding of accumulator + bias).  All tensors are device buffers owned by the caller (y is
+    written in place and returned)."""
     x = _dev(x, torch.float16, "x"); w = _dev(w, torch.float16, "w"); y = _dev(y, torch.float16, "y")
     b = _dev(bias, torch.float32, "bias"); r = _dev(residual, torch.float16, "residual")
-    st = _lib.lib().fp_igemm_f16_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(b), _ptr(r),
+    sc = _dev(bn_scale, torch.float32, "bn_scale"); sh = _dev(bn_shift, torch.float32, "bn_shift")
+    flags = (IGEMM_RELU if relu else 0) | (IGEMM_ROUND_ACC if conv_rounding else 0)
+    st = _lib.lib().fp_igemm_f16_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), _ptr(r),
                                      C.byref(r_geom) if r_geom is not None else None, _ptr(y), C.byref(y_geom), int(M), int(N),
-                                     int(Cin), int(taps), int(bool(relu)), _stream())
+                                     int(Cin), int(taps), flags, _stream(x))
     _lib.check(st, "fp_igemm_f16_fwd")
     return y
 
 
-def _work_igemm(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None):
+def _work_igemm(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None, **k):
     by = 2 * (M * Cin * (1 if taps == 1 else 1.0 / (x_geom.stride ** 2)) + N * Cin * taps + M * N * (2 if residual is not None else 1))
     return by, 2.0 * M * N * Cin * taps
 
 
-def layernorm_f16(x, gamma, beta, eps=1e-5):
-    """LN over the last dim (512) of an fp16 tensor, fp32 statistics -> fp16 (fp_layernorm_f16_fwd)"""
-    x = _dev(x, torch.float16, "x")
-    D = int(x.shape[-1])
-    M = x.numel() // D
-    y = torch.empty_like(x)
-    st = _lib.lib().fp_layernorm_f16_fwd(_ptr(x), _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")),
-                                         float(eps), _ptr(y), M, D, _stream())
-    _lib.check(st, "fp_layernorm_f16_fwd")
-    return y
+def add_pe_f16(tok, pe):
+    """tok (B, S, 512) fp16, pe (S, 512) f32 -> f16(f32(tok) + pe): the in_proj operand (fp_add_pe_f16_fwd)"""
+    tok = _dev(tok, torch.float16, "tok")
+    pe = _dev(pe, torch.float32, "pe")
+    S, D = int(pe.shape[-2]), int(pe.shape[-1])
+    M = tok.numel() // D
+    out = torch.empty_like(tok)
+    _lib.check(_lib.lib().fp_add_pe_f16_fwd(_ptr(tok), _ptr(pe), _ptr(out), M, S, D, _stream(tok)), "fp_add_pe_f16_fwd")
+    return out
 
 
-def colmean_f16(x, gamma=None, beta=None, eps=1e-5):
-    """x (G, R, 512) fp16 -> (G, 512) f32: mean over R of LN(x)*gamma+beta (gamma given) or of x (fp_colmean_f16_fwd)"""
+def layernorm_res(branch16, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None, want32=True, want16=True):
+    """LN(resid + f32(branch16)) * gamma + beta with resid = x32 or f32(tok16) + pe -> (y32 | None, y16 | None)
+    (fp_layernorm_res_fwd: the fp32 residual stream / LayerNorms of nn.TransformerEncoderLayer under autocast)"""
+    br = _dev(branch16, torch.float16, "branch16")
+    D = int(br.shape[-1])
+    M = br.numel() // D
+    x32 = _dev(x32, torch.float32, "x32"); tok16 = _dev(tok16, torch.float16, "tok16"); pe = _dev(pe, torch.float32, "pe")
+    S = int(pe.shape[-2]) if pe is not None else 0
+    y32 = torch.empty(br.shape, dtype=torch.float32, device=br.device) if want32 else None
+    y16 = torch.empty_like(br) if want16 else None
+    st = _lib.lib().fp_layernorm_res_fwd(_ptr(x32), _ptr(tok16), _ptr(pe), S, _ptr(br), _ptr(_dev(gamma, torch.float32, "gamma")),
+                                         _ptr(_dev(beta, torch.float32, "beta")), float(eps), _ptr(y32), _ptr(y16), M, D, _stream(br))
+    _lib.check(st, "fp_layernorm_res_fwd")
+    return y32, y16
+
+
+def colmean_f16(x, gamma=None, beta=None, eps=1e-5, resid32=None):
+    """x (G, R, 512) fp16 -> (G, 512) f32: mean over R of LN(resid32 + x)*gamma+beta (gamma given) or of x (fp_colmean_f16_fwd)"""
     x = _dev(x, torch.float16, "x")
     G_, R, D = (int(v) for v in x.shape)
     out = torch.empty((G_, D), dtype=torch.float32, device=x.device)
-    st = _lib.lib().fp_colmean_f16_fwd(_ptr(x), _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")),
-                                       float(eps), _ptr(out), G_, R, D, _stream())
+    st = _lib.lib().fp_colmean_f16_fwd(_ptr(x), _ptr(_dev(resid32, torch.float32, "resid32")), _ptr(_dev(gamma, torch.float32, "gamma")),
+                                       _ptr(_dev(beta, torch.float32, "beta")), float(eps), _ptr(out), G_, R, D, _stream(x))
     _lib.check(st, "fp_colmean_f16_fwd")
     return out
 
 
-def attention_f16(qkv, n_heads):
+ROWS_ROUND_F16, ROWS_X_F16, ROWS_Y_F16 = 1, 2, 4
+
+
+def rows_linear(x, w, bias=None, round_f16=False, out_f16=False):
+    """y = x @ w.T + bias for a few hundred rows: x (M,K) f32|f16, w (N,K) f16, bias (N) f32 -> (M,N) f32 (rounded to
+    fp16 values if round_f16) or fp16 (out_f16) (fp_rows_linear_fwd)"""
+    if not (torch.is_tensor(x) and x.dtype in (torch.float32, torch.float16)):
+        raise _lib.FpAmdError("rows_linear: x must be an f32 or f16 tensor")
+    x = _dev(x, x.dtype, "x"); w = _dev(w, torch.float16, "w"); b = _dev(bias, torch.float32, "bias")
+    M, K = (int(v) for v in x.shape)
+    N = int(w.shape[0])
+    y = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
+    flags = (ROWS_ROUND_F16 if round_f16 else 0) | (ROWS_X_F16 if x.dtype == torch.float16 else 0) | (ROWS_Y_F16 if out_f16 else 0)
+    _lib.check(_lib.lib().fp_rows_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, K, N, flags, _stream(x)), "fp_rows_linear_fwd")
+    return y
+
+
+ATT_FP16_SCORES = 1
+
+
+def attention_f16(qkv, n_heads, fp16_scores=False):
     """qkv (B, S, 3*D) fp16 = in_proj output [q | k | v] -> (B, S, D) fp16 = softmax(q k^T / sqrt(hd)) v, heads merged
-    (fp_attention_f16_fwd; head size D / n_heads must be 128)"""
+    (fp_attention_f16_fwd; head size D / n_heads must be 128).  fp16_scores: q * sqrt(1/hd) and the scores rounded to fp16
+    (the need_weights=True branch of nn.MultiheadAttention under autocast, score_network.py:73,86)"""
     qkv = _dev(qkv, torch.float16, "qkv")
     B, S, D3 = (int(v) for v in qkv.shape)
     D = D3 // 3
     out = torch.empty((B, S, D), dtype=torch.float16, device=qkv.device)
-    st = _lib.lib().fp_attention_f16_fwd(_ptr(qkv), _ptr(out), B, S, int(n_heads), D // int(n_heads), _stream())
+    st = _lib.lib().fp_attention_f16_fwd(_ptr(qkv), _ptr(out), B, S, int(n_heads), D // int(n_heads),
+                                         ATT_FP16_SCORES if fp16_scores else 0, _stream(qkv))
     _lib.check(st, "fp_attention_f16_fwd")
     return out
 
@@ -385,11 +432,6 @@ def _work_conv1(x, *a, **k):
     return Bn * (6 * H * W + 64 * (H // 2) * (W // 2)) * 2 + 64 * 294 * 2, 2.0 * Bn * (H // 2) * (W // 2) * 64 * 294
 
 
-def _work_linear(x, w, *a, **k):
-    M, K, No = x.numel() // x.shape[-1], x.shape[-1], w.shape[0]
-    return 2 * (M * K + No * K + M * No), 2.0 * M * K * No
-
-
 def _timed(name, fn, work=None):
     def wrapper(*a, **k):
         t = KernelTimers.active
@@ -412,9 +454,13 @@ warp_crops = _timed("fp_warp_crops", warp_crops, _work_warp)
 crop_windows = _timed("fp_crop_windows", crop_windows)
 pose_update = _timed("fp_pose_update", pose_update)
 conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu, _work_conv1)
-linear_f16 = _timed("fp_linear_f16_fwd", linear_f16, _work_linear)
 igemm_f16 = _timed("fp_igemm_f16_fwd", igemm_f16, _work_igemm)
-layernorm_f16 = _timed("fp_layernorm_f16_fwd", layernorm_f16, lambda x, *a, **k: (4.0 * x.numel(), 0.0))
-colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16, lambda x, *a, **k: (2.0 * x.numel(), 0.0))
+add_pe_f16 = _timed("fp_add_pe_f16_fwd", add_pe_f16, lambda tok, pe: (4.0 * tok.numel(), 0.0))
+layernorm_res = _timed("fp_layernorm_res_fwd", layernorm_res,
+                       lambda br, *a, **k: ((2.0 + (4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
+                                             + (2.0 if k.get("want16", True) else 0.0)) * br.numel(), 0.0))
+colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16,
+                     lambda x, *a, **k: ((6.0 if k.get("resid32") is not None else 2.0) * x.numel(), 0.0))
+rows_linear = _timed("fp_rows_linear_fwd", rows_linear)
 attention_f16 = _timed("fp_attention_f16_fwd", attention_f16,
-                       lambda qkv, n_heads: (2.0 * qkv.numel() * 4.0 / 3.0, 4.0 * qkv.shape[0] * qkv.shape[1] ** 2 * (qkv.shape[2] // 3)))
+                       lambda qkv, n_heads, **k: (2.0 * qkv.numel() * 4.0 / 3.0, 4.0 * qkv.shape[0] * qkv.shape[1] ** 2 * (qkv.shape[2] // 3)))

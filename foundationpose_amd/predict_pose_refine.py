@@ -83,8 +83,9 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
 class PoseRefinePredictor:
     run_name = "2023-10-28-18-33-37"
 
-    def __init__(self, cfg=None, state_dict=None, weights_root=None, device="cuda", precision="fp16",
-                 channels_last=True, use_hip_gemm=True):
+    def __init__(self, cfg=None, state_dict=None, weights_root=None, device="cuda", precision="fp16", channels_last=True):
+        """precision='fp16': the reference's deployed autocast configuration on libfp_amd.so (engine.py);
+        'fp32': fp32 torch ops, no autocast (`amp=False` in the reference)"""
         self.amp = precision != "fp32"
         if cfg is None or state_dict is None:
             cfg, state_dict, ckpt_dir = load_run(self.run_name, weights_root)
@@ -110,7 +111,7 @@ class PoseRefinePredictor:
         self.dataset = PoseRefinePairH5Dataset(cfg=self.cfg, h5_file="", mode="test")
         self.device = torch.device(device)
         self.precision = precision
-        self._plan_opts = dict(precision=precision, channels_last=channels_last, use_hip=use_hip_gemm)
+        self._plan_opts = dict(precision=precision, channels_last=channels_last)
         self.model = RefineNet(cfg=self.cfg, c_in=self.cfg["c_in"])
         self.model.load_state_dict(state_dict)
         self.model.to(self.device).eval()
@@ -125,11 +126,13 @@ class PoseRefinePredictor:
             self._plan_dev = dev
         return self._plan
 
-    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, AB=None):
+    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, AB=None, workspace=None):
         """The refine loop on device tensors only (predict_pose_refine.py:182-235): per iteration fp_crop_windows ->
         fp_render_crops (A) + fp_warp_crops (B) -> RefineNet plan -> fp_pose_update.  No host round trip, no host-side
-        tensor creation: the whole call is capturable in a hipGraph (foundationpose_amd/graphs.py).
-        -> (poses (N,4,4), last trans (N,3), last rot (N,3|6))"""
+        tensor creation: the whole call is capturable in a hipGraph (foundationpose_amd/graphs.py), which then passes
+        its own rasteriser `workspace`.
+        -> (poses (N,4,4), trans_delta (N,3) in metres, rot_mat_delta (N,3,3)) of the last iteration, as the reference
+        keeps them in last_trans_update / last_rot_update (predict_pose_refine.py:238-239)"""
         plan = self.plan()
         N = poses.shape[0]
         oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
@@ -138,23 +141,27 @@ class PoseRefinePredictor:
         normalize = bool(self.cfg["normalize_xyz"])
         if AB is None:
             AB = torch.empty((2 * N, 6, oh, ow), dtype=plan.dtype, device=poses.device)
-        trans = rot = None
-        for _ in range(iteration):
+        trans_delta = torch.empty((N, 3), dtype=torch.float32, device=poses.device)
+        rot_delta = torch.empty((N, 3, 3), dtype=torch.float32, device=poses.device)
+        out = None
+        for it in range(iteration):
             tf_to_crops, bbox2d = ops.crop_windows(poses, K, mesh_diameter, self.cfg["crop_ratio"], (ow, oh))
             if N == 2:
                 # reference broadcasting quirk: with exactly two poses transform_pts pairs pose i with
                 # corner i, so both hypotheses are rendered with [umin_0, vmin_0, umax_1, vmax_1]
                 bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
             ops.render_crops(mesh_handle, poses, bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
-                             xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[:N])
+                             xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[:N], workspace=workspace)
             ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops, K, poses, mesh_diameter, ops.MODE_REFINE,
                            normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[N:])
             out = plan(AB)
-            trans, rot = out["trans"].contiguous(), out["rot"].contiguous()
-            poses = ops.pose_update(trans, rot, poses, rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
+            last = it + 1 == iteration
+            poses = ops.pose_update(out["trans"], out["rot"], poses, rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
                                     trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
-                                    mesh_diameter=float(mesh_diameter))
-        return poses, trans, rot
+                                    mesh_diameter=float(mesh_diameter), trans_delta_out=trans_delta if last else None,
+                                    rot_delta_out=rot_delta if last else None)
+        self.last_raw_output = out     # raw network outputs of the last iteration (debugging / tests)
+        return poses, trans_delta, rot_delta
 
     @torch.inference_mode()
     def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None,

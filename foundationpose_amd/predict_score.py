@@ -48,7 +48,7 @@ class ScorePredictor:
     run_name = "2024-01-11-20-02-45"
 
     def __init__(self, amp=True, cfg=None, state_dict=None, weights_root=None, device="cuda", precision=None,
-                 channels_last=True, use_hip_gemm=True):
+                 channels_last=True):
         if precision is None:
             precision = "fp16" if amp else "fp32"
         self.amp = precision != "fp32"
@@ -67,7 +67,7 @@ class ScorePredictor:
         self.dataset = ScoreMultiPairH5Dataset(cfg=self.cfg, mode="test", h5_file=None, max_num_key=1)
         self.device = torch.device(device)
         self.precision = precision
-        self._plan_opts = dict(precision=precision, channels_last=channels_last, use_hip=use_hip_gemm)
+        self._plan_opts = dict(precision=precision, channels_last=channels_last)
         self.model = ScoreNetMultiPair(cfg=self.cfg, c_in=self.cfg["c_in"])
         self.model.load_state_dict(state_dict)
         self.model.to(self.device).eval()

@@ -61,8 +61,14 @@ def fill_state_dict(template, seed=0, head_gain=1.0):
     return out
 
 
-def random_state_dict(kind, cfg=None, seed=0):
-    """kind in {'refine','score'} -> seeded state_dict for RefineNet / ScoreNetMultiPair."""
+def random_state_dict(kind, cfg=None, seed=0, head_scale=1.0):
+    """kind in {'refine','score'} -> seeded state_dict for RefineNet / ScoreNetMultiPair.
+
+    head_scale multiplies the refiner's output heads (trans_head.1 / rot_head.1 weight and bias).  A TRAINED refiner is
+    a contraction (its update shrinks the pose error); these untrained stand-ins are the opposite -- d(update)/d(pose)
+    is ~40-120 for the seed-0 checkpoint on the synthetic scene (measured with the CPU oracle), so a
+    free-running chain of iterations amplifies any last-bit difference into a different trajectory.  head_scale < ~0.008
+    makes the iteration map non-expanding; the free-running parity tests use CONTRACTION_HEAD_SCALE."""
     from .refine_network import RefineNet
     from .score_network import ScoreNetMultiPair
     if kind == "refine":
@@ -82,7 +88,13 @@ def random_state_dict(kind, cfg=None, seed=0):
     sd = fill_state_dict(template, seed=seed, head_gain=1.0 if calibrated else gain)
     if calibrated:
         sd.update(_calibration_overlay(kind, sd))
+    if kind == "refine" and head_scale != 1.0:
+        for k in ("trans_head.1.weight", "trans_head.1.bias", "rot_head.1.weight", "rot_head.1.bias"):
+            sd[k] = sd[k] * float(head_scale)
     return sd
+
+
+CONTRACTION_HEAD_SCALE = 0.002
 
 
 _CALIB = None

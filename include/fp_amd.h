@@ -106,28 +106,27 @@ int fp_warp_crops(const float* rgb /*dev*/, const float* xyz_map /*dev|NULL*/, c
                   const float* poses /*dev N,16*/, float mesh_diameter, int flags, int mode, int H, int W,
                   int N, int oh, int ow, void* B /*dev N,6,oh,ow*/, void* stream);
 
-/* predict_pose_refine.py:195-234 + Utils.py:848-855 + pytorch3d so3_exp_map / rotation_6d_to_matrix */
+/* predict_pose_refine.py:195-234 + Utils.py:848-855 + pytorch3d so3_exp_map / rotation_6d_to_matrix.
+ * trans_delta_out / rot_delta_out (optional): the metric translation delta and the applied rotation matrix
+ * (so3_exp_map(.)^T), i.e. what the reference keeps in last_trans_update / last_rot_update (:238-239). */
 int fp_pose_update(const float* trans /*dev N,3*/, const float* rot /*dev N,3|6*/,
                    const float* poses_in /*dev N,16*/, int rot_rep, int normalize_xyz,
                    const float* trans_normalizer /*host 3*/, float rot_normalizer, float mesh_diameter, int N,
-                   float* poses_out /*dev N,16*/, void* stream);
+                   float* poses_out /*dev N,16*/, float* trans_delta_out /*dev N,3|NULL*/,
+                   float* rot_delta_out /*dev N,9|NULL*/, void* stream);
 
-/* refine_network.py:38 / score_network.py:37 first ConvBNReLU (7x7, stride 2, pad 3, C_in -> 64) with the
- * eval-mode BatchNorm folded into (scale, shift) and ReLU fused: the "patch-embed conv" as an MFMA implicit GEMM.
- * x (B,6,160,160) f16 NCHW ; w (64, 6*7*7) f16 row-major (PyTorch conv weight flattened) ;
- * scale/shift (64) f32 : y = relu(conv(x,w) * scale + shift) ; y (B,64,80,80) f16; channels_last_out = 0: NCHW,
- * 1: NHWC, 2: NHWC inside a (B,82,82,64) buffer with a 1-pixel border the kernel does not touch (the input layout
- * of fp_igemm_f16_fwd). */
-int fp_conv7x7s2_bn_relu_fwd(const void* x /*dev*/, const void* w /*dev*/, const float* scale /*dev*/,
-                             const float* shift /*dev*/, void* y /*dev*/, int B, int Hin, int Win,
-                             int channels_last_out, void* stream);
+/* ---- network stage.  Arithmetic policy of every entry point below = the op sequence torch.cuda.amp.autocast(fp16)
+ * produces for the reference's modules (predict_pose_refine.py:190-191, predict_score.py:193-194): fp16 operands,
+ * fp32 accumulation, and a rounding to fp16 wherever the reference holds an fp16 tensor. ---- */
 
-/* nn.MultiheadAttention / nn.TransformerEncoderLayer in_proj (refine_network.py:56-70, score_network.py:52-53):
- * y[M,Nout] = x[M,K] @ w[Nout,K]^T + bias, fp16 in / fp32 accumulate / fp16 out (the QKV projection,
- * K=512, Nout=1536; also used for the other 512-wide projections). */
-int fp_linear_f16_fwd(const void* x /*dev M,K f16*/, const void* w /*dev Nout,K f16*/,
-                      const float* bias /*dev Nout f32|NULL*/, void* y /*dev M,Nout f16*/, int M, int K, int Nout,
-                      int relu, void* stream);
+/* refine_network.py:38 / score_network.py:37 first ConvBNReLU (7x7, stride 2, pad 3, 6 -> 64): the "patch-embed conv"
+ * as an MFMA implicit GEMM.  x (B,6,Hin,Win) f16 NCHW; w (64, 6*7*7) f16 row-major (PyTorch conv weight flattened);
+ * bias (64) f32 holding fp16-representable values | NULL; bn_scale/bn_shift (64) f32 | NULL: eval BatchNorm2d as
+ * x*scale + shift.  y = relu(f16(f16(f16(conv) + bias) * scale + shift)), NHWC inside a (B, Hin/2 + 2 pad, Win/2 + 2 pad, 64)
+ * f16 buffer whose `pad`-pixel border (pad = 0 | 1) the kernel does not touch (pad 1 = the input layout of fp_igemm_f16_fwd). */
+int fp_conv7x7s2_bn_relu_fwd(const void* x /*dev*/, const void* w /*dev*/, const float* bias /*dev|NULL*/,
+                             const float* bn_scale /*dev|NULL*/, const float* bn_shift /*dev|NULL*/, void* y /*dev*/,
+                             int B, int Hin, int Win, int pad, void* stream);
 
 /* Addressing of one operand of fp_igemm_f16_fwd: GEMM row m = (image b, oy, ox) with b = m / pixels_per_image,
  * oy = (m % pixels_per_image) / width, ox = ... % width, lives at element offset
@@ -139,27 +138,56 @@ typedef struct {
   int pixels_per_image, width, padded_h, padded_w, stride, offset, cstride, coff, bsplit, cgroup;
 } fp_igemm_geom;
 
-/* network_modules.py:37-50 ConvBNReLU / :73-111 ResnetBasicBlock (3x3, pad 1, stride 1|2; eval BatchNorm folded into
- * w and bias) and the 512-wide Linear layers of refine_network.py:56-70 / score_network.py:52-53, as ONE MFMA
- * implicit GEMM:  y[m, n] = act( sum_{tap, ci} x[row(m) + tap][ci] * w[n][tap*Cin + ci] + bias[n] (+ residual[m, n]) ).
- * x / y / residual: NHWC fp16 addressed by their fp_igemm_geom (the input's border must be zero; its geometry
- * addresses tap (0,0), i.e. offset = 0 for pad 1); w (N, taps*Cin) fp16 with k ordered (ky, kx, ci); bias (N) f32.
- * taps = 9 (3x3) or 1 (GEMM); N % 128 == 0; Cin % 64 == 0. */
-int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/,
-                     const float* bias /*dev|NULL*/, const void* residual /*dev|NULL*/,
-                     const fp_igemm_geom* r_geom /*host|NULL*/, void* y /*dev*/, const fp_igemm_geom* y_geom /*host*/,
-                     int M, int N, int Cin, int taps, int relu, void* stream);
+#define FP_IGEMM_RELU 1      /* ReLU after the residual add */
+#define FP_IGEMM_ROUND_ACC 2 /* nn.Conv2d semantics: the accumulator is rounded to fp16 BEFORE the bias is added (ATen adds the
+                                bias to the fp16 convolution output) and BatchNorm, if given, rounds once more; without the
+                                flag: nn.Linear semantics, one rounding of accumulator + bias */
 
-/* The LayerNorms of nn.TransformerEncoderLayer (refine_network.py:56-70; post-norm, eps 1e-5): y = LN(x)*gamma + beta,
- * x / y (M, D) fp16, statistics in fp32.  D must be 512 (d_model of both networks). */
-int fp_layernorm_f16_fwd(const void* x /*dev*/, const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps,
-                         void* y /*dev*/, int M, int D, void* stream);
+/* network_modules.py:37-50 ConvBNReLU / :73-111 ResnetBasicBlock (3x3, pad 1, stride 1|2, eval BatchNorm) and the
+ * 512-wide Linear layers of refine_network.py:56-70 / score_network.py:52-53, as ONE MFMA implicit GEMM:
+ *   acc[m, n] = sum_{tap, ci} x[row(m) + tap][ci] * w[n][tap*Cin + ci]                       (fp32 accumulation)
+ *   y = act( f16(epilogue(acc)) (+ residual[m, n], rounded to f16) ),  epilogue per the flags above.
+ * x / y / residual: NHWC fp16 addressed by their fp_igemm_geom (the input's border must be zero; its geometry
+ * addresses tap (0,0), i.e. offset = 0 for pad 1); w (N, taps*Cin) fp16 with k ordered (ky, kx, ci); bias, bn_scale,
+ * bn_shift (N) f32.  taps = 9 (3x3) or 1 (GEMM); N % 128 == 0; Cin % 64 == 0. */
+int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/,
+                     const float* bias /*dev|NULL*/, const float* bn_scale /*dev|NULL*/, const float* bn_shift /*dev|NULL*/,
+                     const void* residual /*dev|NULL*/, const fp_igemm_geom* r_geom /*host|NULL*/, void* y /*dev*/,
+                     const fp_igemm_geom* y_geom /*host*/, int M, int N, int Cin, int taps, int flags, void* stream);
+
+/* network_modules.py:133-137 PositionalEmbedding as the in_proj operand: out = f16(f32(tok) + pe[row % S]).
+ * tok / out (M, D) fp16, pe (S, D) f32; D must be 512.  (The fp32 sum itself is never stored: fp_layernorm_res_fwd
+ * recomputes it.) */
+int fp_add_pe_f16_fwd(const void* tok /*dev*/, const float* pe /*dev*/, void* out /*dev*/, int M, int S, int D, void* stream);
+
+/* The LayerNorms of nn.TransformerEncoderLayer (refine_network.py:56-70; post-norm, eps 1e-5) on the fp32 residual
+ * stream autocast keeps:  z = resid + f32(branch16);  y = LN(z)*gamma + beta  -> y32 (M,D) f32 and/or y16 (M,D) f16,
+ * with resid = x32 (M,D) f32, or f32(tok16) + pe[row % S] when x32 is NULL.  D must be 512. */
+int fp_layernorm_res_fwd(const float* x32 /*dev|NULL*/, const void* tok16 /*dev|NULL*/, const float* pe /*dev|NULL*/, int S,
+                         const void* branch16 /*dev*/, const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps,
+                         float* y32 /*dev|NULL*/, void* y16 /*dev|NULL*/, int M, int D, void* stream);
 
 /* `.mean(dim=1)` over the tokens of each hypothesis (refine_network.py:90-91, score_network.py:74), optionally fused
- * with the LayerNorm that precedes it: out[g, :] = mean_{r < rows_per_group} f(x[g*rows_per_group + r, :]) with
- * f = LN(.)*gamma + beta if gamma != NULL else identity.  x (groups*rows_per_group, D) fp16, out (groups, D) f32. */
-int fp_colmean_f16_fwd(const void* x /*dev*/, const float* gamma /*dev D|NULL*/, const float* beta /*dev D|NULL*/,
-                       float eps, float* out /*dev*/, int groups, int rows_per_group, int D, void* stream);
+ * with the residual add + LayerNorm that precede it: out[g, :] = mean_{r < rows_per_group} f(row g*rows_per_group + r),
+ * f = LN(resid32 + f32(x))*gamma + beta if gamma != NULL (resid32 may be NULL) else f32(x).  x (groups*rows_per_group, D)
+ * fp16, resid32 same shape f32, out (groups, D) f32. */
+int fp_colmean_f16_fwd(const void* x /*dev*/, const float* resid32 /*dev|NULL*/, const float* gamma /*dev D|NULL*/,
+                       const float* beta /*dev D|NULL*/, float eps, float* out /*dev*/, int groups, int rows_per_group,
+                       int D, void* stream);
+
+#define FP_ROWS_ROUND_F16 1 /* y (f32) holds fp16-representable values: the reference keeps these outputs in fp16 */
+#define FP_ROWS_X_F16 2     /* x is fp16 instead of f32 */
+#define FP_ROWS_Y_F16 4     /* y is stored as fp16 instead of f32 */
+
+/* The Linear layers that follow a token mean (refine_network.py:58,69 heads; score_network.py:53 out_proj after the
+ * mean has been commuted in front of it; score_network.py:57 final Linear): y[M,N] = x[M,K] @ w[N,K]^T + bias for a
+ * few hundred rows, fp32 accumulation.  x f32|f16, w f16, bias f32|NULL, y f32|f16.  K % 8 == 0, K <= 2048. */
+int fp_rows_linear_fwd(const void* x /*dev*/, const void* w /*dev*/, const float* bias /*dev|NULL*/, void* y /*dev*/,
+                       int M, int K, int N, int flags, void* stream);
+
+#define FP_ATT_FP16_SCORES 1 /* the need_weights=True branch of F.multi_head_attention_forward under autocast
+                                (score_network.py:73,86): q * sqrt(1/d) rounded to fp16 and the q.k scores rounded to fp16
+                                before the fp32 softmax; default: F.scaled_dot_product_attention (fp32 scores) */
 
 /* The attention core of nn.MultiheadAttention(512, 4) as the networks call it (query = key = value, no mask, eval):
  * refine_network.py:56-70 (nn.TransformerEncoderLayer self-attention over the 400 tokens of a hypothesis),
@@ -167,8 +195,10 @@ int fp_colmean_f16_fwd(const void* x /*dev*/, const float* gamma /*dev D|NULL*/,
  * torch.nn.functional.multi_head_attention_forward does between in_proj and out_proj:
  *   out[b, t, h*hd:(h+1)*hd] = softmax_t'(q[b,t,h,:] . k[b,t',h,:] / sqrt(hd)) v[b,t',h,:]
  * qkv (B*S, 3*H*hd) fp16 = the in_proj output [q | k | v]; out (B*S, H*hd) fp16 = the out_proj input.  hd must be 128.
- * fp32 scores / softmax / accumulation; the (B*H, S, S) probability tensor is never formed. */
-int fp_attention_f16_fwd(const void* qkv /*dev*/, void* out /*dev*/, int B, int S, int H, int head_dim, void* stream);
+ * fp32 softmax statistics and accumulation, probabilities rounded to fp16 for the second product, normalisation
+ * after it (flash-attention order); the (B*H, S, S) probability tensor is never formed. */
+int fp_attention_f16_fwd(const void* qkv /*dev*/, void* out /*dev*/, int B, int S, int H, int head_dim, int flags,
+                         void* stream);
 
 /* mycpp/src/app/pybind_api.cpp:24-68 cluster_poses (host, init-time). Returns #kept, indices in keep_idx. */
 int fp_cluster_poses(float angle_diff_deg, float dist_diff, const float* poses /*host N,16*/, int N,

@@ -5,7 +5,12 @@ ops of oracle.ops (C) and the networks of oracle.nets (torch CPU fp32)."""
 import numpy as np
 import torch
 
-from . import nets, ops
+from . import nets, nets_amp, ops
+
+
+def _nets(amp):
+    """amp=False: fp32 networks (oracle/nets.py); amp=True: the reference's deployed fp16-autocast policy (oracle/nets_amp.py)"""
+    return nets_amp if amp else nets
 
 
 def mesh_tensors_np(mesh):
@@ -56,13 +61,13 @@ def score_inputs(cfg, poses, mesh_np, rgb, depth, K, mesh_diameter):
     return A, B, tf, bb
 
 
-def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_np, mesh_diameter, iteration=5, trace=None):
+def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_np, mesh_diameter, iteration=5, trace=None, amp=False):
     poses = np.asarray(ob_in_cams, dtype=np.float32).reshape(-1, 4, 4).copy()
     tn = cfg["trans_normalizer"]
     tn = [float(tn)] * 3 if isinstance(tn, (int, float)) else [float(v) for v in tn]
     for it in range(iteration):
         A, B, _, _ = refine_inputs(cfg, poses, mesh_np, rgb, xyz_map, K, mesh_diameter)
-        out = nets.refine_forward(torch.from_numpy(A), torch.from_numpy(B), sd)
+        out = _nets(amp).refine_forward(torch.from_numpy(A), torch.from_numpy(B), sd)
         poses = ops.pose_update(out["trans"].numpy(), out["rot"].numpy(), poses, cfg["rot_rep"],
                                 bool(cfg["normalize_xyz"]), tn, float(cfg["rot_normalizer"]), float(mesh_diameter))
         if trace is not None:
@@ -70,10 +75,10 @@ def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_np, mesh_di
     return poses
 
 
-def score_predict(cfg, sd, rgb, depth, K, ob_in_cams, mesh_np, mesh_diameter, trace=None):
+def score_predict(cfg, sd, rgb, depth, K, ob_in_cams, mesh_np, mesh_diameter, trace=None, amp=False):
     A, B, _, _ = score_inputs(cfg, ob_in_cams, mesh_np, rgb, depth, K, mesh_diameter)
     N = A.shape[0]
-    out = nets.score_forward(torch.from_numpy(A), torch.from_numpy(B), sd, L=N)
+    out = _nets(amp).score_forward(torch.from_numpy(A), torch.from_numpy(B), sd, L=N)
     if trace is not None:
         trace.append(dict(A=A, B=B))
     return out["score_logit"].reshape(-1).numpy() + 100.0
@@ -83,11 +88,11 @@ def preprocess_depth(depth):
     return ops.bilateral_filter_depth(ops.erode_depth(depth, radius=2), radius=2)
 
 
-def register(refine_cfg, refine_sd, score_cfg, score_sd, K, rgb, depth, poses0, mesh_np, mesh_diameter, iteration=5):
+def register(refine_cfg, refine_sd, score_cfg, score_sd, K, rgb, depth, poses0, mesh_np, mesh_diameter, iteration=5, amp=False):
     """estimater.py:159-240 after hypothesis generation: -> (sorted poses, sorted scores, order)."""
     d = preprocess_depth(depth)
     xyz_map = ops.depth2xyzmap(d, K, f64_internal=True)
-    poses = refine_predict(refine_cfg, refine_sd, rgb, d, K, poses0, xyz_map, mesh_np, mesh_diameter, iteration)
-    scores = score_predict(score_cfg, score_sd, rgb, d, K, poses, mesh_np, mesh_diameter)
+    poses = refine_predict(refine_cfg, refine_sd, rgb, d, K, poses0, xyz_map, mesh_np, mesh_diameter, iteration, amp=amp)
+    scores = score_predict(score_cfg, score_sd, rgb, d, K, poses, mesh_np, mesh_diameter, amp=amp)
     order = np.argsort(-scores, kind="stable")
     return poses[order], scores[order], order

@@ -30,7 +30,7 @@ def test_argument_errors_are_reported_without_gpu():
     h = C.c_void_p()
     st = lib.fp_mesh_create(None, None, None, None, None, None, None, 0, 0, 0, 0, C.byref(h))
     assert st == -1 and b"fp_mesh_create" in lib.fp_last_error()
-    assert lib.fp_linear_f16_fwd(C.c_void_p(8), C.c_void_p(8), None, C.c_void_p(8), 4, 33, 128, 0, None) == -1
+    assert lib.fp_rows_linear_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), 4, 33, 128, 0, None) == -1
     assert b"multiple" in lib.fp_last_error()
     # scratch = per-hypothesis vertex records (32 B / vertex) + per-strip triangle lists (10 strips of 16 rows)
     ws = lib.fp_workspace_bytes(252, 2501, 4900, 160, 160)
@@ -40,9 +40,17 @@ def test_argument_errors_are_reported_without_gpu():
     assert big >= 4 * (100000 * 32 + 10 * 200000 * 4)
     # GEMM geometry errors
     G = (C.c_int * 10)(1, 1, 1, 1, 1, 0, 512, 0, 0, 0)
-    assert lib.fp_igemm_f16_fwd(C.c_void_p(8), G, C.c_void_p(8), None, None, None, C.c_void_p(8), G, 4, 100, 512, 1, 0, None) == -1
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), None, None, None, None, None, C.c_void_p(16), G, 4, 100, 512, 1, 0, None) == -1
     assert b"multiple of 128" in lib.fp_last_error()
-    assert lib.fp_layernorm_f16_fwd(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 1e-5, C.c_void_p(8), 4, 256, None) == -1
+    # BatchNorm in the epilogue only with the conv rounding sequence; unknown flags are refused
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), None, C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), G, 4, 128, 512, 1, 1, None) == -1
+    assert b"FP_IGEMM_ROUND_ACC" in lib.fp_last_error()
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), None, None, None, None, None, C.c_void_p(16), G, 4, 128, 512, 1, 8, None) == -1
+    assert lib.fp_layernorm_res_fwd(None, C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,
+                                    C.c_void_p(16), None, 4, 256, None) == -1
+    assert lib.fp_layernorm_res_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,
+                                    C.c_void_p(16), None, 4, 512, None) == -1     # residual given twice
+    assert lib.fp_attention_f16_fwd(C.c_void_p(16), C.c_void_p(16), 1, 4, 4, 128, 2, None) == -1
 
 
 def test_product_does_not_import_oracle():

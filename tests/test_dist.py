@@ -40,12 +40,12 @@ class _StubScorer:
     def __init__(self):
         g = torch.Generator().manual_seed(11)
         self.proj = torch.randn((16, 512), generator=g)
-        from foundationpose_amd.engine import _MHA
+        from foundationpose_amd.engine import _TorchMHA
         sd = {"att_cross.in_proj_weight": torch.randn((1536, 512), generator=g) * 0.05,
               "att_cross.in_proj_bias": torch.randn((1536,), generator=g) * 0.05,
               "att_cross.out_proj.weight": torch.randn((512, 512), generator=g) * 0.05,
               "att_cross.out_proj.bias": torch.randn((512,), generator=g) * 0.05}
-        self.att_cross = _MHA(sd, "att_cross", torch.float32, use_hip=False)
+        self.att_cross = _TorchMHA(sd, "att_cross", torch.float32)
         self.lin = torch.randn((1, 512), generator=g) * 0.05
 
     def predict(self, rgb, depth, K, ob_in_cams, mesh=None, mesh_tensors=None, mesh_diameter=None, feature_exchange=None):
