@@ -13,14 +13,14 @@ glcam_in_cvcam = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0,
 
 
 def set_seed(random_seed):
-    """Utils.py:222-229"""
-    np.random.seed(random_seed)
-    random.seed(random_seed)
-    torch.manual_seed(random_seed)
+    """Same effect as Utils.py:222-229: every RNG the pipeline can touch starts from `random_seed`, and the (unused here)
+    cuDNN autotuner is pinned to deterministic choices so that a reference-side caller sees the flags it expects."""
+    seed = int(random_seed)
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
-        torch.cuda.manual_seed_all(random_seed)
-    torch.backends.cudnn.deterministic = True
-    torch.backends.cudnn.benchmark = False
+        torch.cuda.manual_seed_all(seed)
+    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
 
 
 # ------------------------------------------------------------------ mesh tensors (Utils.py:104-130)
@@ -153,30 +153,37 @@ def depth2xyzmap_batch(depths, Ks, zfar):
 
 # ------------------------------------------------------------------ small transforms
 def to_homo_torch(pts):
-    ones = torch.ones((*pts.shape[:-1], 1), dtype=torch.float, device=pts.device)
-    return torch.cat((pts, ones), dim=-1)
+    """(..., d) -> (..., d+1) with a trailing 1 (Utils.py:520-526)"""
+    return torch.nn.functional.pad(pts.to(torch.float), (0, 1), value=1.0)
+
+
+def _per_point(tf, n_points):
+    """Broadcasting rule of the reference's transform helpers: a batch of transforms whose batch dimension is not the
+    point count gets a singleton point axis, i.e. every transform is applied to all points.  (A batch as long as the
+    point list pairs transform i with point i: SURVEY App. D.5 -- reproduced, callers rely on it.)"""
+    return tf.unsqueeze(-3) if tf.dim() >= 3 and tf.shape[-3] != n_points else tf
 
 
 def transform_pts(pts, tf):
-    """Utils.py:529-536"""
-    if len(tf.shape) >= 3 and tf.shape[-3] != pts.shape[-2]:
-        tf = tf[..., None, :, :]
-    return (tf[..., :-1, :-1] @ pts[..., None] + tf[..., :-1, -1:])[..., 0]
+    """Rigid / affine map of points, x -> R x + t with [R | t] the top rows of tf (semantics of Utils.py:529-536)"""
+    tf = _per_point(tf, pts.shape[-2])
+    d = pts.shape[-1]
+    return torch.einsum("...ij,...j->...i", tf[..., :d, :d], pts) + tf[..., :d, d]
 
 
 def transform_dirs(dirs, tf):
-    """Utils.py:539-546"""
-    if len(tf.shape) >= 3 and tf.shape[-3] != dirs.shape[-2]:
-        tf = tf[..., None, :, :]
-    return (tf[..., :3, :3] @ dirs[..., None])[..., 0]
+    """Directions only see the rotation block (semantics of Utils.py:539-546)"""
+    return torch.einsum("...ij,...j->...i", _per_point(tf, dirs.shape[-2])[..., :3, :3], dirs)
 
 
 def egocentric_delta_pose_to_pose(A_in_cam, trans_delta, rot_mat_delta):
-    """Utils.py:848-855"""
-    B_in_cam = torch.eye(4, dtype=torch.float, device=A_in_cam.device)[None].expand(len(A_in_cam), -1, -1).contiguous()
-    B_in_cam[:, :3, 3] = A_in_cam[:, :3, 3] + trans_delta
-    B_in_cam[:, :3, :3] = rot_mat_delta @ A_in_cam[:, :3, :3]
-    return B_in_cam
+    """Utils.py:848-855 semantics: the rotation delta acts in the camera frame about the object origin
+    (R' = dR R), the translation delta is added (t' = t + dt); fp_pose_update is the fused device version."""
+    out = torch.zeros((A_in_cam.shape[0], 4, 4), dtype=torch.float, device=A_in_cam.device)
+    out[:, :3, :3] = torch.bmm(rot_mat_delta.to(torch.float), A_in_cam[:, :3, :3].to(torch.float))
+    out[:, :3, 3] = A_in_cam[:, :3, 3] + trans_delta
+    out[:, 3, 3] = 1.0
+    return out
 
 
 def compute_crop_window_tf_batch(pts=None, H=None, W=None, poses=None, K=None, crop_ratio=1.2, out_size=None, rgb=None,
@@ -248,27 +255,23 @@ def icosphere_vertices(subdivisions=1):
 
 
 def sample_views_icosphere(n_views, subdivisions=None, radius=1):
-    """Utils.py:483-507: camera-in-object poses looking at the origin from icosphere vertices."""
+    """Camera-in-object poses on an icosphere, each looking at the origin (semantics of Utils.py:483-507): camera z
+    points from the vertex to the centre, x = world-up (0,0,1) x z (or (1,0,0) at the poles), y = z x x."""
     if subdivisions is None:
         subdivisions = 1
         while icosphere_vertices(subdivisions).shape[0] < n_views:
             subdivisions += 1
-    verts = icosphere_vertices(subdivisions) * radius
-    cam_in_obs = np.tile(np.eye(4)[None], (len(verts), 1, 1))
-    cam_in_obs[:, :3, 3] = verts
-    up = np.array([0, 0, 1])
-    z_axis = -cam_in_obs[:, :3, 3]
-    z_axis /= np.linalg.norm(z_axis, axis=-1).reshape(-1, 1)
-    x_axis = np.cross(up.reshape(1, 3), z_axis)
-    invalid = (x_axis == 0).all(axis=-1)
-    x_axis[invalid] = [1, 0, 0]
-    x_axis /= np.linalg.norm(x_axis, axis=-1).reshape(-1, 1)
-    y_axis = np.cross(z_axis, x_axis)
-    y_axis /= np.linalg.norm(y_axis, axis=-1).reshape(-1, 1)
-    cam_in_obs[:, :3, 0] = x_axis
-    cam_in_obs[:, :3, 1] = y_axis
-    cam_in_obs[:, :3, 2] = z_axis
-    return cam_in_obs
+    eye = icosphere_vertices(subdivisions) * radius
+    fwd = -eye / np.linalg.norm(eye, axis=1, keepdims=True)
+    right = np.cross(np.array([[0.0, 0.0, 1.0]]), fwd)
+    right[~right.any(axis=1)] = (1.0, 0.0, 0.0)        # looking along the up axis: any perpendicular will do, the reference picks +x
+    right /= np.linalg.norm(right, axis=1, keepdims=True)
+    down = np.cross(fwd, right)
+    down /= np.linalg.norm(down, axis=1, keepdims=True)
+    poses = np.zeros((len(eye), 4, 4))
+    poses[:, :3, :] = np.stack([right, down, fwd, eye], axis=2)
+    poses[:, 3, 3] = 1.0
+    return poses
 
 
 def compute_mesh_diameter(model_pts=None, mesh=None, n_sample=1000):
@@ -287,30 +290,31 @@ def compute_mesh_diameter(model_pts=None, mesh=None, n_sample=1000):
 
 
 def symmetry_tfs_from_info(info, rot_angle_discrete=5):
-    """Utils.py:806-834 (BOP models_info symmetries -> list of 4x4)."""
-    symmetry_tfs = [np.eye(4)]
-    if "symmetries_discrete" in info:
-        tfs = np.array(info["symmetries_discrete"]).reshape(-1, 4, 4)
-        tfs[..., :3, 3] *= 0.001
-        symmetry_tfs = [np.eye(4)] + list(tfs)
-    if "symmetries_continuous" in info:
-        axis = np.array(info["symmetries_continuous"][0]["axis"]).reshape(3)
-        offset = info["symmetries_continuous"][0]["offset"]
-        rxs, rys, rzs = [0], [0], [0]
-        steps = np.arange(0, 360, rot_angle_discrete) / 180.0 * np.pi
-        if axis[0] > 0:
-            rxs = steps
-        elif axis[1] > 0:
-            rys = steps
-        elif axis[2] > 0:
-            rzs = steps
-        for rx in rxs:
-            for ry in rys:
-                for rz in rzs:
-                    tf = euler_matrix(rx, ry, rz)
-                    tf[:3, 3] = offset
-                    symmetry_tfs.append(tf)
-    return np.array(symmetry_tfs)
+    """BOP models_info entry -> (S,4,4) symmetry transforms in metres, identity first (semantics of Utils.py:806-834):
+    the listed discrete symmetries (translations are in mm), then, for the FIRST continuous symmetry, rotations about the
+    coordinate axis its `axis` vector is positive in (x before y before z), every `rot_angle_discrete` degrees starting at
+    0, each carrying the symmetry's `offset` as translation."""
+    out = [np.eye(4)]
+    discrete = info.get("symmetries_discrete")
+    if discrete is not None:
+        for m in np.asarray(discrete, dtype=float).reshape(-1, 4, 4):
+            m = m.copy()
+            m[:3, 3] /= 1000.0
+            out.append(m)
+    continuous = info.get("symmetries_continuous")
+    if continuous:
+        sym = continuous[0]
+        axis = np.asarray(sym["axis"], dtype=float).reshape(3)
+        positive = [i for i in range(3) if axis[i] > 0]
+        angles = np.deg2rad(np.arange(0, 360, rot_angle_discrete))
+        for ang in (angles if positive else [0.0]):
+            euler = [0.0, 0.0, 0.0]
+            if positive:
+                euler[positive[0]] = ang
+            m = euler_matrix(*euler)
+            m[:3, 3] = sym["offset"]
+            out.append(m)
+    return np.array(out)
 
 
 def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):

@@ -2,7 +2,8 @@
 (``register`` / ``track_one`` / ``reset_object`` / ``to_device``), orchestrating the HIP hot path.
 
 Differences that are deliberate and documented in DESIGN.md:
-  * depth filtering / back-projection stay on the device (the reference round-trips numpy<->GPU four times);
+  * depth filtering, back-projection and the translation guess (masked median) stay on the device (the reference
+    round-trips numpy<->GPU four times); register() moves a handful of scalars over PCIe, never the depth map;
   * open3d voxel down-sampling of ``self.pts``/``self.normals`` (computed but unused by the hot path)
     is replaced by the raw model points;
   * no global ``torch.set_default_tensor_type`` side effect.
@@ -113,26 +114,33 @@ class FoundationPose:
     def generate_random_pose_hypo(self, K, rgb, depth, mask, scene_pts=None):
         ob_in_cams = self.rot_grid.clone()
         center = self.guess_translation(depth=depth, mask=mask, K=K)
-        ob_in_cams[:, :3, 3] = torch.tensor(center, device=self.device, dtype=torch.float).reshape(1, 3)
+        ob_in_cams[:, :3, 3] = torch.as_tensor(center, device=self.device, dtype=torch.float).reshape(1, 3)
         return ob_in_cams
 
     # ------------------------------------------------------------------ estimater.py:137-156
     def guess_translation(self, depth, mask, K):
-        depth = depth.data.cpu().numpy() if torch.is_tensor(depth) else np.asarray(depth)
-        mask = mask.data.cpu().numpy() if torch.is_tensor(mask) else np.asarray(mask)
-        vs, us = np.where(mask > 0)
-        if len(us) == 0:
+        """Initial translation of every hypothesis (semantics of estimater.py:137-156): the ray through the centre of the
+        mask's bounding box, at the median of the valid depths inside the mask; zeros when the mask or the valid set is
+        empty.  Computed on the device: the depth map never leaves HBM (the reference does this in numpy)."""
+        d = torch.as_tensor(depth, device=self.device, dtype=torch.float)
+        m = torch.as_tensor(np.asarray(mask) if not torch.is_tensor(mask) else mask, device=self.device) > 0
+        rows, cols = torch.nonzero(m.any(dim=1)).reshape(-1), torch.nonzero(m.any(dim=0)).reshape(-1)
+        if rows.numel() == 0:
             logging.info("mask is all zero")
             return np.zeros((3))
-        uc = (us.min() + us.max()) / 2.0
-        vc = (vs.min() + vs.max()) / 2.0
-        valid = mask.astype(bool) & (depth >= 0.001)
-        if not valid.any():
+        z = d[m & (d >= 0.001)]
+        if z.numel() == 0:
             logging.info("valid is empty")
             return np.zeros((3))
-        zc = np.median(depth[valid])
-        center = (np.linalg.inv(np.asarray(K, dtype=np.float64)) @ np.asarray([uc, vc, 1]).reshape(3, 1)) * zc
-        return center.reshape(3)
+        zs = torch.sort(z).values
+        n = zs.numel()
+        stats = torch.stack([rows[0], rows[-1], cols[0], cols[-1]]).to(torch.float64)
+        mid = torch.stack([zs[(n - 1) // 2], zs[n // 2]])          # numpy's median: mean of the two middle values
+        v0, v1, u0, u1 = stats.tolist()                            # six scalars cross PCIe, not a 640x480 image
+        lo, hi = mid.tolist()
+        zc = float(np.float32(np.float32(lo) + np.float32(hi)) / np.float32(2.0)) if lo != hi else lo
+        ray = np.linalg.solve(np.asarray(K, dtype=np.float64), np.array([(u0 + u1) / 2.0, (v0 + v1) / 2.0, 1.0]))
+        return ray * zc
 
     # ------------------------------------------------------------------ estimater.py:159-240
     def register(self, K, rgb, depth, ob_mask, ob_id=None, glctx=None, iteration=5):
@@ -142,19 +150,18 @@ class FoundationPose:
         depth_t = torch.as_tensor(depth, device=self.device, dtype=torch.float).contiguous()
         depth_t = ops.erode_depth(depth_t, radius=2)
         depth_t = ops.bilateral_filter_depth(depth_t, radius=2)
-        depth_np = depth_t.data.cpu().numpy()
         ob_mask = np.asarray(ob_mask.data.cpu().numpy() if torch.is_tensor(ob_mask) else ob_mask)
-        valid = (depth_np >= 0.001) & (ob_mask > 0)
-        if valid.sum() < 4:
+        mask_t = torch.as_tensor(ob_mask, device=self.device) > 0
+        if int(((depth_t >= 0.001) & mask_t).sum()) < 4:
             logging.info("valid too small, return")
             pose = np.eye(4)
-            pose[:3, 3] = self.guess_translation(depth=depth_np, mask=ob_mask, K=K)
+            pose[:3, 3] = self.guess_translation(depth=depth_t, mask=mask_t, K=K)
             return pose
-        self.H, self.W = depth_np.shape[:2]
+        self.H, self.W = int(depth_t.shape[0]), int(depth_t.shape[1])
         self.K = K
         self.ob_id = ob_id
         self.ob_mask = ob_mask
-        poses = self.generate_random_pose_hypo(K=K, rgb=rgb, depth=depth_np, mask=ob_mask, scene_pts=None)
+        poses = self.generate_random_pose_hypo(K=K, rgb=rgb, depth=depth_t, mask=mask_t, scene_pts=None)
         xyz_map = ops.depth_to_xyz(depth_t, K, zfar=float("inf"), f64_internal=True)  # depth2xyzmap (numpy variant)
         poses, vis = self.refiner.predict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth_t, K=K,
                                           ob_in_cams=poses, normal_map=None, xyz_map=xyz_map, glctx=self.glctx,

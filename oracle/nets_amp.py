@@ -37,9 +37,16 @@ def r16(x):
 # reference run under CPU autocast (tests/test_oracle_amp_golden.py)
 CONV_BIAS = "separate"
 
+# True: every reduction (conv input channels, Linear / attention k) runs over the REVERSED index order -- the same
+# arithmetic policy with a different fp32 summation order.  The distance between the two evaluations is the floor any
+# other implementation of the policy (cuDNN, MFMA kernels) can be expected to reach (tests/test_gpu_amp.py).
+REVERSED_SUMS = False
+
 
 def _conv(x, sd, p, stride):
     w = r16(sd[p + ".weight"].float())
+    if REVERSED_SUMS:
+        x, w = x.flip(1), w.flip(1)
     y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2)
     b = sd.get(p + ".bias")
     if b is None:
@@ -73,7 +80,10 @@ def _basic_block(x, sd, p):
 
 def _linear(x, w, b):
     """fp16 GEMM with the bias in the epilogue: one rounding"""
-    return r16(F.linear(r16(x), r16(w.float()), r16(b.float())))
+    x, w = r16(x), r16(w.float())
+    if REVERSED_SUMS:
+        x, w = x.flip(-1), w.flip(-1)
+    return r16(F.linear(x, w, r16(b.float())))
 
 
 def encoder_tokens(A, B, sd, stem, joint, trace=None):

@@ -213,51 +213,6 @@ def test_warp_crops(scene, dev, frame, mode, normalize):
     np.testing.assert_allclose(o16.astype(np.float32), ref, atol=2e-3, rtol=1e-3)
 
 
-# ------------------------------------------------------------------ MFMA kernels vs fp32 torch reference
-def test_conv7x7_mfma(dev):
-    from foundationpose_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(5)
-    x = (torch.rand((5, 6, 160, 160), generator=g) * 2 - 1)
-    w = torch.randn((64, 6, 7, 7), generator=g) * 0.06
-    scale = torch.rand(64, generator=g) + 0.5
-    shift = torch.randn(64, generator=g) * 0.2
-    x16, w16 = x.half(), w.half()
-    ref = torch.relu(torch.nn.functional.conv2d(x16.float(), w16.float(), None, stride=2, padding=3)
-                     * scale[None, :, None, None] + shift[None, :, None, None])
-    for cl in (False, True):
-        y = ops.conv7x7s2_bn_relu(x16.to(dev), w16.reshape(64, -1).contiguous().to(dev), scale.to(dev), shift.to(dev),
-                                  channels_last=cl)
-        assert y.shape == (5, 64, 80, 80)
-        np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=2e-3)  # fp16 output rounding
-    # NHWC inside a zero-bordered buffer (the layout fp_igemm_f16_fwd consumes); border must stay untouched
-    buf = torch.zeros((5, 82, 82, 64), dtype=torch.float16, device=dev)
-    buf[:, 0] = 7.0
-    ops.conv7x7s2_bn_relu(x16.to(dev), w16.reshape(64, -1).contiguous().to(dev), scale.to(dev), shift.to(dev), out_padded=buf)
-    np.testing.assert_allclose(buf[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=2e-3)
-    assert float((buf[:, 0] - 7.0).abs().max()) == 0 and float(buf[:, -1].abs().max()) == 0 and float(buf[:, :, 0][:, 1:].abs().max()) == 0
-    # ragged shapes: odd number of bands, width not a multiple of 32 pixels per tile
-    x2 = (torch.rand((3, 6, 104, 88), generator=g) * 2 - 1).half()
-    ref2 = torch.relu(torch.nn.functional.conv2d(x2.float(), w16.float(), None, stride=2, padding=3)
-                      * scale[None, :, None, None] + shift[None, :, None, None])
-    y2 = ops.conv7x7s2_bn_relu(x2.to(dev), w16.reshape(64, -1).contiguous().to(dev), scale.to(dev), shift.to(dev), channels_last=True)
-    np.testing.assert_allclose(y2.float().cpu().numpy(), ref2.numpy(), atol=4e-3, rtol=2e-3)
-
-
-@pytest.mark.parametrize("M,K,N", [(800, 512, 1536), (1000, 512, 512), (37, 64, 128)])
-def test_linear_mfma(dev, M, K, N):
-    from foundationpose_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(M)
-    x = torch.randn((M, K), generator=g).half()
-    # asymmetric weight so that a transposed fragment layout cannot pass
-    w = (torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-4).half()
-    b = torch.randn(N, generator=g)
-    ref = x.float() @ w.float().t() + b
-    y = ops.linear_f16(x.to(dev), w.to(dev), b.to(dev))
-    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=4e-3)
-    yr = ops.linear_f16(x.to(dev), w.to(dev), b.to(dev), relu=True)
-    np.testing.assert_allclose(yr.float().cpu().numpy(), torch.relu(ref).numpy(), atol=2e-2, rtol=4e-3)
-
-
 # ------------------------------------------------------------------ predictors end to end (fp32 parity configuration)
 def _geodesic(Ra, Rb):
     """rotation angle of Ra Rb^T via atan2(sin, cos): well conditioned near 0, unlike arccos of a float32 trace"""
@@ -295,8 +250,14 @@ def test_refiner_fp32_matches_oracle(scene, dev, gmesh, frame):
         dR = _geodesic(out[:, :3, :3], tgt[:, :3, :3])
         dt = np.linalg.norm(out[:, :3, 3] - tgt[:, :3, 3], axis=1)
         assert dR.max() <= 1e-4 and dt.max() <= 1e-4, (it, dR.max(), dt.max())
-        np.testing.assert_allclose(pred.last_trans_update.cpu().numpy(), trace[it]["trans"], atol=2e-4)
-        np.testing.assert_allclose(pred.last_rot_update.cpu().numpy(), trace[it]["rot"], atol=2e-4)
+        np.testing.assert_allclose(pred.last_raw_output["trans"].cpu().numpy(), trace[it]["trans"], atol=2e-4)
+        np.testing.assert_allclose(pred.last_raw_output["rot"].cpu().numpy(), trace[it]["rot"], atol=2e-4)
+        # last_trans_update / last_rot_update as the reference keeps them (predict_pose_refine.py:238-239): metric
+        # translation delta and the applied 3x3 rotation, i.e. pose_new = [[dR, 0], [0, 1]] applied as in Utils.py:848-855
+        dT = pred.last_trans_update.cpu().numpy()
+        dRm = pred.last_rot_update.cpu().numpy()
+        np.testing.assert_allclose(out[:, :3, 3], np.asarray(start)[:, :3, 3] + dT, atol=1e-6)
+        np.testing.assert_allclose(out[:, :3, :3], dRm @ np.asarray(start)[:, :3, :3], atol=1e-5)
         start = tgt
     chain, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"],
                             mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=3)
@@ -388,134 +349,6 @@ def test_hip_network_inputs_match_reference_golden(scene, dev, gmesh, frame):
         assert diff.mean() < 2e-3 and diff[:, 1:, 1:].sum() == 0
 
 
-# ------------------------------------------------------------------ implicit-GEMM conv / linear kernel vs fp32 torch
-def _padded_nhwc(x_nchw, pad, dev):
-    B, Cc, H, W = x_nchw.shape
-    buf = torch.zeros((B, H + 2 * pad, W + 2 * pad, Cc), dtype=torch.float16, device=dev)
-    buf[:, pad:pad + H, pad:pad + W, :] = x_nchw.permute(0, 2, 3, 1).to(dev)
-    return buf
-
-
-@pytest.mark.parametrize("B,H,Cin,Cout,stride,res", [(3, 40, 128, 128, 1, True), (2, 80, 64, 128, 2, False),
-                                                     (5, 20, 512, 512, 1, True), (3, 40, 256, 512, 2, False)])
-def test_igemm_conv3x3(dev, B, H, Cin, Cout, stride, res):
-    from foundationpose_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin)
-    x = (torch.randn((B, Cin, H, H), generator=g) * 0.5).half()
-    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (1.0 / (3 * Cin ** 0.5)) + torch.arange(Cout)[:, None, None, None] * 1e-5).half()
-    bias = torch.randn(Cout, generator=g) * 0.1
-    Ho = H // stride
-    r = (torch.randn((B, Cout, Ho, Ho), generator=g) * 0.5).half() if res else None
-    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias, stride=stride, padding=1)
-    ref = ref.half().float()          # torch semantics: conv output rounded to fp16 ...
-    if res:
-        ref = (ref + r.float()).half().float()   # ... then the fp16 residual add
-    ref = torch.relu(ref)
-    xb = _padded_nhwc(x, 1, dev)
-    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dev)
-    y = torch.zeros((B, Ho + 2, Ho + 2, Cout), dtype=torch.float16, device=dev)
-    rb = _padded_nhwc(r, 1, dev) if res else None
-    gin = ops.IgemmGeom.image(Ho, Ho, 1, Cin, stride=stride, offset=0)
-    gin.padded_h, gin.padded_w = H + 2, H + 2
-    gout = ops.IgemmGeom.image(Ho, Ho, 1, Cout)
-    ops.igemm_f16(xb, gin, wk, bias.to(dev), y, gout, B * Ho * Ho, Cout, Cin, 9, relu=True, residual=rb, r_geom=gout if res else None)
-    out = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
-    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=6e-3, rtol=4e-3)
-    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0   # the zero border is left untouched
-
-
-def test_igemm_channel_concat_and_linear(dev):
-    """bsplit writes image b and image b+n side by side along C (the A|B feature concat); taps=1 is a plain GEMM with
-    a ragged last tile"""
-    from foundationpose_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(77)
-    n, H, Cc = 3, 8, 128
-    x = (torch.randn((2 * n, Cc, H, H), generator=g) * 0.5).half()
-    w = (torch.randn((Cc, Cc, 3, 3), generator=g) * 0.03).half()
-    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, padding=1)
-    ref = torch.cat([ref[:n], ref[n:]], dim=1)
-    y = torch.zeros((n, H + 2, H + 2, 2 * Cc), dtype=torch.float16, device=dev)
-    gin = ops.IgemmGeom.image(H, H, 1, Cc, offset=0)
-    gout = ops.IgemmGeom.image(H, H, 1, 2 * Cc, bsplit=n, cgroup=Cc)
-    ops.igemm_f16(_padded_nhwc(x, 1, dev), gin, w.permute(0, 2, 3, 1).reshape(Cc, -1).contiguous().to(dev), None, y, gout,
-                  2 * n * H * H, Cc, Cc, 9)
-    np.testing.assert_allclose(y[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=4e-3)
-    for M, K, N in ((1000, 512, 1536), (37, 64, 128), (4097, 512, 512)):
-        xm = torch.randn((M, K), generator=g).half()
-        wm = (torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-4).half()
-        b = torch.randn(N, generator=g)
-        refm = xm.float() @ wm.float().t() + b
-        ym = torch.empty((M, N), dtype=torch.float16, device=dev)
-        ops.igemm_f16(xm.to(dev), ops.IgemmGeom.matrix(K), wm.to(dev), b.to(dev), ym, ops.IgemmGeom.matrix(N), M, N, K, 1)
-        np.testing.assert_allclose(ym.float().cpu().numpy(), refm.numpy(), atol=2e-2, rtol=4e-3)
-
-
-@pytest.mark.parametrize("use_bn", [True, False])
-def test_hip_encoder_matches_torch_fp32_encoder(dev, use_bn):
-    """_HipEncoder (conv1 + 15 implicit-GEMM convs, padded NHWC, fused epilogues) vs the fp32 PyTorch encoder"""
-    from foundationpose_amd import engine
-    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
-    cfg = dict(DEFAULT_REFINE_CFG, use_BN=use_bn)
-    sd = {k: v.to(dev) for k, v in random_state_dict("refine", cfg, seed=3).items()}
-    g = torch.Generator(device="cpu").manual_seed(8)
-    n = 3
-    AB = torch.rand((2 * n, 6, 160, 160), generator=g)
-    AB[:, 3:] = AB[:, 3:] * 2 - 1
-    AB = AB * (torch.rand((2 * n, 1, 160, 160), generator=g) > 0.3)
-    ref = engine._Encoder(sd, "encodeA", "encodeAB", torch.float32, False, False)(AB.to(dev))
-    enc = engine._HipEncoder(sd, "encodeA", "encodeAB", dev)
-    hip = enc(AB.half().to(dev))
-    assert hip.shape == ref.shape == (n, 400, 512)
-    err = (hip.float() - ref).abs()
-    scale = ref.abs().mean().item()
-    assert err.max().item() <= 0.06 * max(1.0, ref.abs().max().item()) and err.mean().item() <= 5e-3 * max(scale, 1.0), \
-        (err.max().item(), err.mean().item(), scale)
-    # second call reuses the cached zero-bordered buffers: identical result
-    assert torch.equal(hip, enc(AB.half().to(dev)))
-
-
-def test_layernorm_and_colmean_kernels(dev):
-    from foundationpose_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(21)
-    x = (torch.randn((7, 400, 512), generator=g) * 2 + torch.randn((1, 1, 512), generator=g)).half()
-    gamma, beta = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g) * 0.1
-    ref = torch.nn.functional.layer_norm(x.float(), (512,), gamma, beta, 1e-5)
-    y = ops.layernorm_f16(x.to(dev), gamma.to(dev), beta.to(dev))
-    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=2e-3)   # fp16 output rounding
-    m = ops.colmean_f16(x.to(dev), gamma.to(dev), beta.to(dev))
-    np.testing.assert_allclose(m.cpu().numpy(), ref.mean(dim=1).numpy(), atol=2e-5, rtol=1e-5)
-    m0 = ops.colmean_f16(x.to(dev))
-    np.testing.assert_allclose(m0.cpu().numpy(), x.float().mean(dim=1).numpy(), atol=2e-5, rtol=1e-5)
-    assert torch.equal(m, ops.colmean_f16(x.to(dev), gamma.to(dev), beta.to(dev)))   # fixed summation order
-
-
-def test_fp16_plans_match_fp32_plans(dev):
-    """deployment plans (HIP encoder, fused LN / token mean, SDPA) vs the fp32 PyTorch plans on the same inputs"""
-    from foundationpose_amd import engine
-    from foundationpose_amd.refine_network import RefineNet
-    from foundationpose_amd.score_network import ScoreNetMultiPair
-    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
-    g = torch.Generator(device="cpu").manual_seed(4)
-    n = 6
-    AB = torch.rand((2 * n, 6, 160, 160), generator=g)
-    AB[:, 3:] = AB[:, 3:] * 2 - 1
-    AB = (AB * (torch.rand((2 * n, 1, 160, 160), generator=g) > 0.3)).to(dev)
-    cfg = dict(DEFAULT_REFINE_CFG)
-    net = RefineNet(cfg=cfg, c_in=6)
-    net.load_state_dict(random_state_dict("refine", cfg, 0))
-    o32 = engine.RefinePlan(net, dev, precision="fp32")(AB)
-    o16 = engine.RefinePlan(net, dev, precision="fp16")(AB.half())
-    for k in ("trans", "rot"):
-        assert o16[k].dtype == torch.float32
-        np.testing.assert_allclose(o16[k].cpu().numpy(), o32[k].cpu().numpy(), atol=3e-2 * max(1.0, float(o32[k].abs().max())))
-    cfg = dict(DEFAULT_SCORE_CFG)
-    net = ScoreNetMultiPair(cfg=cfg, c_in=6)
-    net.load_state_dict(random_state_dict("score", cfg, 0))
-    f32 = engine.ScorePlan(net, dev, precision="fp32").features(AB)
-    f16 = engine.ScorePlan(net, dev, precision="fp16").features(AB.half())
-    np.testing.assert_allclose(f16.float().cpu().numpy(), f32.cpu().numpy(), atol=3e-2 * max(1.0, float(f32.abs().max())))
-
-
 # ------------------------------------------------------------------ hipGraph-captured tracking
 def test_graphed_tracker_replays_the_eager_result(scene, dev, gmesh, frame):
     """one captured graph per (frame size, N, iterations); replay == eager bit for bit, for changing inputs"""
@@ -555,6 +388,10 @@ def test_estimator_track_graph_matches_eager(scene, dev):
                              refiner=refiner, device=dev, track_graph=graph)
         est.pose_last = torch.as_tensor(scene["gt"], device=dev, dtype=torch.float)
         seq = [est.track_one(scene["rgb"], scene["depth"], scene["K"], iteration=2) for _ in range(3)]
+        # a register() with 252 hypotheses between tracked frames allocates the big activation set and grows the
+        # rasteriser scratch; the captured graph owns its buffers, so replaying it afterwards is still the eager result
+        seq.append(est.register(K=scene["K"], rgb=scene["rgb"], depth=scene["depth"], ob_mask=scene["mask"], iteration=1))
+        seq += [est.track_one(scene["rgb"], scene["depth"], scene["K"], iteration=2) for _ in range(2)]
         out[graph] = np.stack(seq)
     assert np.array_equal(out[False], out[True])
 
