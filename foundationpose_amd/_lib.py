@@ -27,7 +27,7 @@ SIGNATURES = {
     "fp_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "fp_render_crops": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "fp_warp_crops": (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
-    "fp_pose_update": (ci, [vp, vp, vp, ci, ci, vp, cf, cf, ci, vp, vp, vp, vp]),
+    "fp_pose_update": (ci, [vp, vp, vp, ci, ci, vp, cf, cf, ci, vp, vp, vp, ci, vp, vp, cf, vp]),
     "fp_conv7x7s2_bn_relu_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "fp_add_pe_f16_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp]),

@@ -136,16 +136,39 @@ struct fp_f3 { float v[3]; };
 __global__ void k_pose_update(const float* __restrict__ trans, const float* __restrict__ rot,
                               const float* __restrict__ poses_in, int rot_rep, int normalize_xyz, fp_f3 tn,
                               float rot_normalizer, float mesh_diameter, int N, float* __restrict__ poses_out,
-                              float* __restrict__ trans_delta_out, float* __restrict__ rot_delta_out) {
+                              float* __restrict__ trans_delta_out, float* __restrict__ rot_delta_out, int trans_rep, fp_k9 K,
+                              const float* __restrict__ tf_to_crops, float input_w) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float dt[3];
+  if (trans_rep == FP_TRANS_DEEPIM) {
+    // predict_pose_refine.py:201-215: (trans.x, trans.y) = shift of the projected object centre in crop pixels / crop
+    // width, trans.z = new depth / current depth.  tf_to_crops = [[sx,0,tx],[0,sy,ty],[0,0,1]], K upper triangular:
+    // both inverses in closed form.
+    const float* A = poses_in + (size_t)n * 16;
+    const float* tf = tf_to_crops + (size_t)n * 9;
+    const float tx = A[3], ty = A[7], tz = A[11];
+    const float u = (K.v[0] * tx + K.v[1] * ty + K.v[2] * tz) / tz, v = (K.v[4] * ty + K.v[5] * tz) / tz;
+    const float uc = tf[0] * u + tf[1] * v + tf[2], vc = tf[3] * u + tf[4] * v + tf[5];
+    const float z_pred = trans[n * 3 + 2] * tz;
+    const float ucp = uc + trans[n * 3] * input_w, vcp = vc + trans[n * 3 + 1] * input_w;
+    const float vp = (vcp - tf[5]) / tf[4];
+    const float up = ((ucp - tf[2]) - tf[1] * vp) / tf[0];
+    const float yn = (vp - K.v[5]) / K.v[4];
+    const float xn = ((up - K.v[2]) - K.v[1] * yn) / K.v[0];
+    dt[0] = xn * z_pred - tx; dt[1] = yn * z_pred - ty; dt[2] = z_pred - tz;
+    if (normalize_xyz) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float v = trans[n * 3 + c];
-    if (!normalize_xyz) v = tanhf(v) * tn.v[c];
-    else v = v * (mesh_diameter / 2.0f);
-    dt[c] = v;
+      for (int c = 0; c < 3; ++c) dt[c] *= (mesh_diameter / 2.0f);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = trans[n * 3 + c];
+      if (!normalize_xyz) v = tanhf(v) * tn.v[c];
+      else v = v * (mesh_diameter / 2.0f);
+      dt[c] = v;
+    }
   }
   float R[9];
   if (rot_rep == FP_ROT_AXIS_ANGLE) {
@@ -252,15 +275,21 @@ extern "C" int fp_crop_windows(const float* poses, const double* K, double mesh_
 extern "C" int fp_pose_update(const float* trans, const float* rot, const float* poses_in, int rot_rep,
                               int normalize_xyz, const float* trans_normalizer, float rot_normalizer,
                               float mesh_diameter, int N, float* poses_out, float* trans_delta_out, float* rot_delta_out,
-                              void* stream) {
+                              int trans_rep, const float* K9, const float* tf_to_crops, float input_w, void* stream) {
   FP_REQUIRE(N >= 0, "fp_pose_update: N < 0");
   if (N == 0) return FP_OK;
   FP_REQUIRE(trans && rot && poses_in && poses_out, "fp_pose_update: NULL tensor");
   FP_REQUIRE(rot_rep == FP_ROT_AXIS_ANGLE || rot_rep == FP_ROT_6D, "fp_pose_update: unknown rot_rep %d", rot_rep);
+  FP_REQUIRE(trans_rep == FP_TRANS_TRACKNET || trans_rep == FP_TRANS_DEEPIM, "fp_pose_update: unknown trans_rep %d", trans_rep);
+  FP_REQUIRE(trans_rep != FP_TRANS_DEEPIM || (K9 && tf_to_crops && input_w > 0.f),
+             "fp_pose_update: trans_rep deepim needs K, tf_to_crops and the crop width");
+  fp_k9 Kk = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}};
+  if (K9) for (int i = 0; i < 9; ++i) Kk.v[i] = K9[i];
   fp_f3 tn = {{1.f, 1.f, 1.f}};
   if (trans_normalizer) { tn.v[0] = trans_normalizer[0]; tn.v[1] = trans_normalizer[1]; tn.v[2] = trans_normalizer[2]; }
   hipLaunchKernelGGL(k_pose_update, dim3(fp_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, trans, rot, poses_in,
-                     rot_rep, normalize_xyz, tn, rot_normalizer, mesh_diameter, N, poses_out, trans_delta_out, rot_delta_out);
+                     rot_rep, normalize_xyz, tn, rot_normalizer, mesh_diameter, N, poses_out, trans_delta_out, rot_delta_out,
+                     trans_rep, Kk, tf_to_crops, input_w);
   FP_CHECK_LAUNCH("fp_pose_update");
   return FP_OK;
 }

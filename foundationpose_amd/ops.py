@@ -212,7 +212,9 @@ def warp_crops(rgb, xyz_map, depth, tf_to_crops, K, poses, mesh_diameter, mode, 
 
 
 def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, trans_normalizer=(1.0, 1.0, 1.0),
-                rot_normalizer=1.0, mesh_diameter=1.0, out=None, trans_delta_out=None, rot_delta_out=None):
+                rot_normalizer=1.0, mesh_diameter=1.0, out=None, trans_delta_out=None, rot_delta_out=None, trans_rep="tracknet",
+                K=None, tf_to_crops=None, input_w=0):
+    """fp_pose_update.  trans_rep='deepim' needs K, tf_to_crops (N,3,3) and the crop width (predict_pose_refine.py:201-215)"""
     tr = _dev(trans, torch.float32, "trans")
     ro = _dev(rot, torch.float32, "rot")
     P = _dev(poses, torch.float32, "poses")
@@ -225,10 +227,14 @@ def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, tra
         raise RuntimeError(f"unknown rot_rep {rot_rep}")
     tn = np.ascontiguousarray(np.broadcast_to(np.asarray(trans_normalizer, dtype=np.float32).reshape(-1), (3,)))
     O = out if out is not None else torch.empty_like(P)
+    deepim = trans_rep == "deepim"
+    K9 = _hostK32(K) if deepim else None
+    tf = _dev(tf_to_crops, torch.float32, "tf_to_crops") if deepim else None
     st = _lib.lib().fp_pose_update(_ptr(tr), _ptr(ro), _ptr(P), rr, int(bool(normalize_xyz)),
                                    tn.ctypes.data_as(C.c_void_p), float(rot_normalizer), float(np.float32(mesh_diameter)),
                                    N, _ptr(O), _ptr(_dev(trans_delta_out, torch.float32, "trans_delta_out")),
-                                   _ptr(_dev(rot_delta_out, torch.float32, "rot_delta_out")), _stream(P))
+                                   _ptr(_dev(rot_delta_out, torch.float32, "rot_delta_out")), 1 if deepim else 0,
+                                   K9.ctypes.data_as(C.c_void_p) if deepim else None, _ptr(tf), float(input_w), _stream(P))
     _lib.check(st, "fp_pose_update")
     return O
 

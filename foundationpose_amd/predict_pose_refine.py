@@ -102,8 +102,6 @@ class PoseRefinePredictor:
         for k in ("input_resize", "trans_normalizer", "rot_normalizer"):
             if k not in self.cfg:
                 raise KeyError(f"refiner cfg lacks required key '{k}'")
-        if self.cfg["trans_rep"] != "tracknet":
-            raise NotImplementedError("only trans_rep='tracknet' (the released configuration) is implemented")
         if self.cfg["use_normal"]:
             raise NotImplementedError("use_normal=True is not supported (the released models use c_in=6)")
         if self.cfg["c_in"] != 6:
@@ -159,7 +157,8 @@ class PoseRefinePredictor:
             poses = ops.pose_update(out["trans"], out["rot"], poses, rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
                                     trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
                                     mesh_diameter=float(mesh_diameter), trans_delta_out=trans_delta if last else None,
-                                    rot_delta_out=rot_delta if last else None)
+                                    rot_delta_out=rot_delta if last else None, trans_rep=str(self.cfg["trans_rep"]), K=K,
+                                    tf_to_crops=tf_to_crops, input_w=float(self.cfg["input_resize"][0]))
         self.last_raw_output = out     # raw network outputs of the last iteration (debugging / tests)
         return poses, trans_delta, rot_delta
 

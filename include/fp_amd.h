@@ -41,9 +41,11 @@ typedef enum {
 #define FP_MODE_REFINE 0 /* predict_pose_refine.py:63,72 + PairH5Dataset.transform_batch */
 #define FP_MODE_SCORE 1  /* predict_score.py:89-90 + TripletH5Dataset.transform_depth_to_xyzmap */
 
-/* fp_pose_update rot_rep */
+/* fp_pose_update rot_rep / trans_rep */
 #define FP_ROT_AXIS_ANGLE 0
 #define FP_ROT_6D 1
+#define FP_TRANS_TRACKNET 0 /* cfg['trans_rep'] = 'tracknet' (the released configuration) and the plain `else` branch */
+#define FP_TRANS_DEEPIM 1   /* 'deepim': crop-space shift of the projected centre + depth ratio, predict_pose_refine.py:201-215 */
 
 /* integer z-buffer definition; shared with oracle/fp_oracle.c */
 #define FP_SUBPIXEL_BITS 4
@@ -113,7 +115,8 @@ int fp_pose_update(const float* trans /*dev N,3*/, const float* rot /*dev N,3|6*
                    const float* poses_in /*dev N,16*/, int rot_rep, int normalize_xyz,
                    const float* trans_normalizer /*host 3*/, float rot_normalizer, float mesh_diameter, int N,
                    float* poses_out /*dev N,16*/, float* trans_delta_out /*dev N,3|NULL*/,
-                   float* rot_delta_out /*dev N,9|NULL*/, void* stream);
+                   float* rot_delta_out /*dev N,9|NULL*/, int trans_rep, const float* K9 /*host 9 f32|NULL (deepim)*/,
+                   const float* tf_to_crops /*dev N,9|NULL (deepim)*/, float input_w /*crop width (deepim)*/, void* stream);
 
 /* ---- network stage.  Arithmetic policy of every entry point below = the op sequence torch.cuda.amp.autocast(fp16)
  * produces for the reference's modules (predict_pose_refine.py:190-191, predict_score.py:193-194): fp16 operands,

@@ -163,6 +163,29 @@ def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, tra
     return out.reshape(N, 4, 4)
 
 
+def deepim_trans_delta(trans, poses, K, tf_to_crops, input_w, normalize_xyz, mesh_diameter):
+    """trans_rep='deepim' (predict_pose_refine.py:201-215): the network predicts the shift of the projected object
+    centre in crop pixels (as a fraction of the crop width) and the ratio of the new depth to the current one;
+    -> metric translation delta (N,3) f32.  All arithmetic in float32 like the reference's torch ops."""
+    tr = _f32(trans)
+    t = _f32(poses).reshape(-1, 4, 4)[:, :3, 3]
+    K32 = np.asarray(K, dtype=np.float64).astype(np.float32)
+    tf = _f32(tf_to_crops).reshape(-1, 3, 3)
+    uv = (K32[None] @ t[:, :, None])[:, :, 0]
+    uv = uv / uv[:, 2:3]
+    uv_crop = (tf @ uv[:, :, None])[:, :2, 0]
+    z_pred = tr[:, 2] * t[:, 2]
+    uv_pred_crop = uv_crop + tr[:, :2] * np.float32(input_w)
+    tfi = np.linalg.inv(tf).astype(np.float32)
+    uv_pred = (tfi[:, :2, :2] @ uv_pred_crop[:, :, None])[:, :, 0] + tfi[:, :2, 2]
+    cp = np.concatenate([uv_pred, np.ones((len(uv_pred), 1), np.float32)], axis=1)
+    cp = (np.linalg.inv(K32).astype(np.float32)[None] @ cp[:, :, None])[:, :, 0] * z_pred[:, None]
+    dt = (cp - t).astype(np.float32)
+    if normalize_xyz:
+        dt = dt * np.float32(float(mesh_diameter) / 2)
+    return dt
+
+
 def cluster_poses(angle_diff, dist_diff, poses, symmetry_tfs):
     P = _f32(poses).reshape(-1, 16)
     S = _f32(symmetry_tfs).reshape(-1, 16)

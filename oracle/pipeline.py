@@ -66,10 +66,15 @@ def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_np, mesh_di
     tn = cfg["trans_normalizer"]
     tn = [float(tn)] * 3 if isinstance(tn, (int, float)) else [float(v) for v in tn]
     for it in range(iteration):
-        A, B, _, _ = refine_inputs(cfg, poses, mesh_np, rgb, xyz_map, K, mesh_diameter)
+        A, B, tf, _ = refine_inputs(cfg, poses, mesh_np, rgb, xyz_map, K, mesh_diameter)
         out = _nets(amp).refine_forward(torch.from_numpy(A), torch.from_numpy(B), sd)
-        poses = ops.pose_update(out["trans"].numpy(), out["rot"].numpy(), poses, cfg["rot_rep"],
-                                bool(cfg["normalize_xyz"]), tn, float(cfg["rot_normalizer"]), float(mesh_diameter))
+        if cfg.get("trans_rep", "tracknet") == "deepim":   # predict_pose_refine.py:201-215
+            dt = ops.deepim_trans_delta(out["trans"].numpy(), poses, K, tf, cfg["input_resize"][0], bool(cfg["normalize_xyz"]), mesh_diameter)
+            # the C pose update with an identity translation scale: normalize_xyz=True multiplies by diameter/2 = 1
+            poses = ops.pose_update(dt, out["rot"].numpy(), poses, cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]), 2.0)
+        else:
+            poses = ops.pose_update(out["trans"].numpy(), out["rot"].numpy(), poses, cfg["rot_rep"],
+                                    bool(cfg["normalize_xyz"]), tn, float(cfg["rot_normalizer"]), float(mesh_diameter))
         if trace is not None:
             trace.append(dict(A=A, B=B, trans=out["trans"].numpy(), rot=out["rot"].numpy(), poses=poses.copy()))
     return poses

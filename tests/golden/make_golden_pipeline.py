@@ -105,10 +105,29 @@ def main():
     rp.model = ns.refine_network.RefineNet(cfg=rcfg, c_in=6).eval()
     rp.model.load_state_dict(rsd, strict=True)
     rp.last_trans_update = rp.last_rot_update = None
+    cap = {}
+    hk = rp.model.register_forward_hook(lambda m, i, o: cap.update(A=i[0].detach().clone(), B=i[1].detach().clone(),
+                                                                   trans=o["trans"].detach().clone(), rot=o["rot"].detach().clone()))
     refined, _ = rp.predict(sc["rgb"], d, K, P, xyz_map, mesh=mesh, mesh_tensors=mt, glctx=None, mesh_diameter=diam, iteration=1)
+    hk.remove()
     out["g4_refined_1it"] = refined.numpy().astype(np.float32)
+    # the network's own inputs (first pose, full resolution, fp32: the stand-in network is sensitive enough that an fp16 copy moves its output by 2e-3) and raw outputs inside the reference predictor: separates
+    # "the networks agree" from "the rendered inputs agree" in tests/test_oracle_pipeline_golden.py
+    out["g4_net_A0"] = cap["A"][0].numpy().astype(np.float32)
+    out["g4_net_B0"] = cap["B"][0].numpy().astype(np.float32)
+    out["g4_raw_trans"] = cap["trans"].numpy().astype(np.float32)
+    out["g4_raw_rot"] = cap["rot"].numpy().astype(np.float32)
     out["g4_trans_delta"] = rp.last_trans_update.numpy().astype(np.float32)
     out["g4_rot_mat_delta"] = rp.last_rot_update.numpy().astype(np.float32)
+    # ---- g6: trans_rep='deepim' branch of the reference predictor (predict_pose_refine.py:201-215), one iteration
+    dcfg = Cfg(dict(rcfg, trans_rep="deepim"))
+    rp2 = object.__new__(ns.refine.PoseRefinePredictor)
+    rp2.amp, rp2.cfg, rp2.dataset = False, dcfg, ns.h5_dataset.PoseRefinePairH5Dataset(cfg=dcfg, h5_file="", mode="test")
+    rp2.model = rp.model
+    rp2.last_trans_update = rp2.last_rot_update = None
+    refined2, _ = rp2.predict(sc["rgb"], d, K, P, xyz_map, mesh=mesh, mesh_tensors=mt, glctx=None, mesh_diameter=diam, iteration=1)
+    out["g6_deepim_refined_1it"] = refined2.numpy().astype(np.float32)
+    out["g6_deepim_trans_delta"] = rp2.last_trans_update.numpy().astype(np.float32)
     sp = object.__new__(ns.score.ScorePredictor)
     sp.amp, sp.cfg, sp.dataset = False, scfg, sds
     sp.model = ns.score_network.ScoreNetMultiPair(cfg=scfg, c_in=6).eval()

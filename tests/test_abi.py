@@ -83,3 +83,17 @@ def test_cluster_poses_host_op(scene):
     k2o = oo.cluster_poses(30, 99999, grid, sym)
     assert len(k2) < 252 and np.array_equal(k2, k2o)
     assert np.array_equal(keep, oo.cluster_poses(30, 99999, grid, np.eye(4)[None]))
+
+
+def test_transform_batch_refuses_an_unfused_batch():
+    """the dataset shims pass a batch through only if it carries the fused network-input buffer of this package's
+    make_crop_data_batch; anything else would need the un-fused normalisation (h5_dataset.py:79-170), which is not here"""
+    import pytest
+    from foundationpose_amd.h5_dataset import PoseRefinePairH5Dataset, ScoreMultiPairH5Dataset
+    from foundationpose_amd.pose_dataset import BatchPoseData
+    for ds in (PoseRefinePairH5Dataset(cfg={}, h5_file="", mode="test"), ScoreMultiPairH5Dataset(cfg={}, mode="test")):
+        with pytest.raises(RuntimeError, match="fused"):
+            ds.transform_batch(BatchPoseData(), H_ori=480, W_ori=640, bound=1)
+        b = BatchPoseData()
+        b.AB = object()
+        assert ds.transform_batch(b, H_ori=480, W_ori=640, bound=1) is b

@@ -82,6 +82,38 @@ def test_pose_update(scene, dev):
             np.testing.assert_allclose(out, ref, rtol=0, atol=3e-6)  # tanhf / sinf / cosf ulps
 
 
+def test_pose_update_deepim_and_delta_outputs(scene, dev):
+    """trans_rep='deepim' (predict_pose_refine.py:201-215) and the optional outputs the reference keeps as
+    last_trans_update / last_rot_update (:238-239): metric translation delta and applied 3x3 rotation"""
+    import os
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    rng = np.random.default_rng(4)
+    P = scene["poses"][:64]
+    tr = (rng.normal(size=(64, 3)) * np.array([0.05, 0.05, 0.02]) + np.array([0, 0, 1.0])).astype(np.float32)   # depth ratio ~ 1
+    ro = rng.normal(size=(64, 3)).astype(np.float32)
+    tf_ref, _ = oo.crop_windows(P, scene["K"], scene["diameter"], 1.2, (160, 160))
+    for norm in (True, False):
+        dt_ref = oo.deepim_trans_delta(tr, P, scene["K"], tf_ref, 160, norm, scene["diameter"])
+        ref = oo.pose_update(dt_ref, ro, P, "axis_angle", True, (1, 1, 1), 0.349, 2.0)
+        dt = torch.empty((64, 3), dtype=torch.float32, device=dev)
+        dR = torch.empty((64, 3, 3), dtype=torch.float32, device=dev)
+        out = ops.pose_update(_t(tr, dev), _t(ro, dev), _t(P, dev), "axis_angle", norm, (0.02, 0.02, 0.05), 0.349, scene["diameter"],
+                              trans_delta_out=dt, rot_delta_out=dR, trans_rep="deepim", K=scene["K"], tf_to_crops=_t(tf_ref, dev),
+                              input_w=160).cpu().numpy()
+        np.testing.assert_allclose(dt.cpu().numpy(), dt_ref, rtol=0, atol=2e-5)     # closed-form vs numpy matrix inverses, f32
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out[:, :3, 3], P[:, :3, 3] + dt.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(out[:, :3, :3], dR.cpu().numpy() @ P[:, :3, :3], atol=2e-6)
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_golden.npz")))
+    Pg = g["poses_in"]
+    tfg, _ = oo.crop_windows(Pg, scene["K"], scene["diameter"], 1.2, (160, 160))
+    dt = torch.empty((3, 3), dtype=torch.float32, device=dev)
+    ops.pose_update(_t(g["g4_raw_trans"], dev), _t(g["g4_raw_rot"], dev), _t(Pg, dev), "axis_angle", True, (0.02, 0.02, 0.05), 0.349,
+                    scene["diameter"], trans_delta_out=dt, trans_rep="deepim", K=scene["K"], tf_to_crops=_t(tfg, dev), input_w=160)
+    np.testing.assert_allclose(dt.cpu().numpy(), g["g6_deepim_trans_delta"], atol=5e-6, rtol=1e-5)   # the reference's own numbers
+
+
 # ------------------------------------------------------------------ rasteriser
 @pytest.mark.parametrize("textured", [True, False])
 def test_render_crops_zbuffer_bit_exact(scene, dev, textured):
