@@ -25,9 +25,10 @@
 
 namespace {
 
-constexpr int SW_BM = 256, SW_BK = 32, SW_NSTW = 4;
-constexpr int SW_PROWS = 512;                       // patch rows per buffer: 32 LDS-DMA instructions of 16 rows
-constexpr int SW_PATCH_BYTES = SW_PROWS * SW_BK * 2;
+constexpr int SW_BK = 32, SW_NSTW = 4;
+// patch rows per buffer (LDS-DMA instructions of 16 rows, a multiple of 8 of them): the tile's BM output pixels + halo,
+// see fp_conv3x3_sw_applicable
+constexpr int sw_prows(int BM) { return BM == 256 ? 512 : 768; }
 
 template <int N>
 __device__ __forceinline__ void sw_wait_vm() {
@@ -44,16 +45,20 @@ __device__ __forceinline__ int sw_q(const IgemmGeom& g, int m) {
   return (b * g.Hp + oy) * g.Wp + ox;
 }
 
-template <int BN, int TM>
+// Tile shapes: 256 x 256 (N % 256 == 0: each wave 128 x 64 outputs), 512 x 128 (N = 128: the same 128 x 64 per wave, so the
+// 128-channel stem layers run 16 MFMAs per wave and k-step like the wide layers instead of 8 behind the same barriers).
+template <int BM, int BN, int TM>
 __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
-  constexpr int BM = SW_BM, BK = SW_BK, NW = 8, THREADS = 512;
+  constexpr int BK = SW_BK, NW = 8, THREADS = 512;
   constexpr int NWN = BN / 64;
   static_assert((BM / (32 * TM)) * NWN == NW, "8 waves");
   constexpr int ROWB = BK * 2;                      // 64-byte LDS rows
   constexpr int W_BYTES = BN * ROWB;
+  constexpr int SW_PROWS = sw_prows(BM);
+  constexpr int SW_PATCH_BYTES = SW_PROWS * ROWB;
   constexpr int WI = BN / 16 / NW;                  // weight LDS-DMA instructions per wave and k-step (16 rows each)
-  constexpr int PI = SW_PROWS / 16 / NW;            // patch instructions per wave and chunk (4): one at each of taps 0..3
-  static_assert(WI >= 1 && PI == 4, "tile shape");
+  constexpr int PI = SW_PROWS / 16 / NW;            // patch instructions per wave and chunk: one at each of taps 0..PI-1
+  static_assert(WI >= 1 && PI >= 1 && PI <= 7 && SW_PROWS == PI * 16 * NW, "tile shape");
   constexpr int STAGES_BYTES = 2 * SW_PATCH_BYTES + SW_NSTW * W_BYTES;
   constexpr int LDS_MAIN = ig_lds_main<BM, BN>(STAGES_BYTES);
   auto swz = [](int row) { return (row >> 2) & 3; };
@@ -181,7 +186,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
       // k-step s+3 = (cc, T+3) or (cc+1, T-6)
       if constexpr (T + 3 < 9) stage_w(cc, T + 3, (s + 3) & (SW_NSTW - 1));
       else stage_w(cc + 1, T - 6, (s + 3) & (SW_NSTW - 1));
-      constexpr int NP = (T == 0 || T == 4) ? 1 : ((T >= 1 && T <= 3) ? 2 : 0);
+      // patch pieces are issued at taps 0..PI-1: in flight from this step and the previous one
+      constexpr int NP = (T < PI ? 1 : 0) + ((T >= 1 && T - 1 < PI) ? 1 : 0);
       sw_wait_vm<2 * WI + NP>();
     } else {
       if constexpr (T + 3 < 9) stage_w(cc, T + 3, (s + 3) & (SW_NSTW - 1));
@@ -225,14 +231,14 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
   ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
 }
 
-template <int BN, int TM>
+template <int BM, int BN, int TM>
 int sw_launch(const IgemmParams& p, hipStream_t stream) {
-  constexpr int LDS = ig_lds_main<SW_BM, BN>(2 * SW_PATCH_BYTES + SW_NSTW * BN * SW_BK * 2) + IG_BIAS_LDS;
+  constexpr int LDS = ig_lds_main<BM, BN>(2 * sw_prows(BM) * SW_BK * 2 + SW_NSTW * BN * SW_BK * 2) + IG_BIAS_LDS;
   static_assert(LDS <= 160 * 1024, "does not fit the 160 KiB LDS");
-  const long long tiles = (long long)fp_cdiv(p.M, SW_BM) * (p.N / BN);
+  const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
-  FP_SET_MAX_LDS((k_conv_sw<BN, TM>), LDS);
-  hipLaunchKernelGGL((k_conv_sw<BN, TM>), dim3((unsigned)tiles), dim3(512), LDS, stream, p);
+  FP_SET_MAX_LDS((k_conv_sw<BM, BN, TM>), LDS);
+  hipLaunchKernelGGL((k_conv_sw<BM, BN, TM>), dim3((unsigned)tiles), dim3(512), LDS, stream, p);
   FP_CHECK_LAUNCH("fp_igemm_f16_fwd(conv_sw)");
   return FP_OK;
 }
@@ -240,21 +246,24 @@ int sw_launch(const IgemmParams& p, hipStream_t stream) {
 }  // namespace
 
 // The patch of a tile is the run of padded pixels from tap (0,0) of its first output pixel to tap (2,2) of its last:
-// 255 + 2 per image-row crossing + 2 Wp + 2 per image crossing + 2 Wp + 3.  It has to fit SW_PROWS rows.
+// BM - 1 + 2 per image-row crossing + 2 Wp + 2 per image crossing + 2 Wp + 3.  It has to fit the patch buffer.
+static int sw_tile_rows(const IgemmParams& p) { return (p.N % 256) == 0 ? 256 : 512; }
+
 bool fp_conv3x3_sw_applicable(const IgemmParams& p) {
   const IgemmGeom& g = p.in;
   if (p.taps != 9 || g.stride != 1 || g.off != 0 || g.bsplit != 0) return false;
   if (g.HoWo % g.Wo != 0 || g.Wp != g.Wo + 2 || g.Hp != g.HoWo / g.Wo + 2) return false;
-  if (p.M % g.HoWo != 0 || p.M < 2 * SW_BM) return false;
+  const int BM = sw_tile_rows(p);
+  if (p.M % g.HoWo != 0 || p.M < 2 * BM) return false;
   if (p.Cin % SW_BK != 0 || p.N % 128 != 0) return false;
   const long long bytes = (long long)(p.M / g.HoWo) * g.Hp * g.Wp * g.cstride * 2;
   if (bytes >= (1ll << 31)) return false;           // 32-bit byte offsets in the LDS-DMA source addresses
-  const int row_cross = (SW_BM - 1) / g.Wo + 1, img_cross = (SW_BM - 1) / g.HoWo + 1;
-  const int span = (SW_BM - 1) + 2 * row_cross + (2 * g.Wp + 2) * img_cross + 2 * g.Wp + 3;
-  return span <= SW_PROWS;
+  const int row_cross = (BM - 1) / g.Wo + 1, img_cross = (BM - 1) / g.HoWo + 1;
+  const int span = (BM - 1) + 2 * row_cross + (2 * g.Wp + 2) * img_cross + 2 * g.Wp + 3;
+  return span <= sw_prows(BM);
 }
 
 int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream) {
-  if ((p.N % 256) == 0) return sw_launch<256, 4>(p, stream);
-  return sw_launch<128, 2>(p, stream);
+  if ((p.N % 256) == 0) return sw_launch<256, 256, 4>(p, stream);
+  return sw_launch<512, 128, 4>(p, stream);
 }

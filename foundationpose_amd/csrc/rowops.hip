@@ -140,9 +140,11 @@ __global__ __launch_bounds__(1024) void k_colmean512(const _Float16* __restrict_
   }
 }
 
-// y[m][n] = sum_k x[m][k] * w[n][k] + b[n]: 4 rows of x per workgroup (fp32, in LDS), wave w takes outputs n = w, w+4, ...;
-// a lane owns 8 consecutive k of every 512-wide k block, so a weight row is read as whole 1 KiB lines.
+// y[m][n] = sum_k x[m][k] * w[n][k] + b[n]: a workgroup takes 4 rows of x (fp32, in LDS) and a chunk of RL_COLS outputs,
+// wave w the outputs chunk + w, w+4, ...; a lane owns 8 consecutive k of every 512-wide k block, so a weight row is
+// read as whole 1 KiB lines.
 #define RL_ROWS 4
+#define RL_COLS 32
 template <bool X16, bool Y16>
 __global__ __launch_bounds__(256) void k_rows_linear(const void* __restrict__ Xv, const _Float16* __restrict__ Wt,
                                                      const float* __restrict__ bias, void* __restrict__ Yv, int M, int K, int N,
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(256) void k_rows_linear(const void* __restrict__ Xv
     xs[i] = v;
   }
   __syncthreads();
-  for (int n = wid; n < N; n += 4) {
+  const int n_end = min(N, (int)(blockIdx.y + 1) * RL_COLS);
+  for (int n = blockIdx.y * RL_COLS + wid; n < n_end; n += 4) {
     float acc[RL_ROWS] = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < K; k0 += 512) {
       const int k = k0 + lane * 8;
@@ -238,7 +241,7 @@ extern "C" int fp_rows_linear_fwd(const void* x, const void* w, const float* bia
   FP_REQUIRE(K > 0 && K % 8 == 0 && K <= 2048, "fp_rows_linear_fwd: K=%d must be a multiple of 8 (<= 2048)", K);
   FP_REQUIRE((((size_t)x | (size_t)w) & 15) == 0, "fp_rows_linear_fwd: tensors must be 16-byte aligned");
   FP_REQUIRE((flags & ~(FP_ROWS_ROUND_F16 | FP_ROWS_X_F16 | FP_ROWS_Y_F16)) == 0, "fp_rows_linear_fwd: unknown flags 0x%x", flags);
-  const dim3 grid(fp_cdiv(M, RL_ROWS)), block(256);
+  const dim3 grid(fp_cdiv(M, RL_ROWS), fp_cdiv(N, RL_COLS)), block(256);
   const size_t lds = (size_t)RL_ROWS * K * sizeof(float);
   const int rnd = (flags & FP_ROWS_ROUND_F16) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;

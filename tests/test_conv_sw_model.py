@@ -9,7 +9,7 @@ import pytest
 
 
 def swz(row): return (row >> 2) & 3
-def run(B, Ho, Wo, Cin, m0, TM, NWN, seed=0):
+def run(B, Ho, Wo, Cin, m0, TM, NWN, seed=0, BM=256):
     Hp, Wp = Ho+2, Wo+2
     HoWo = Ho*Wo
     M = B*HoWo
@@ -20,21 +20,23 @@ def run(B, Ho, Wo, Cin, m0, TM, NWN, seed=0):
         b = m // HoWo; r = m - b*HoWo; oy = r // Wo; ox = r - oy*Wo
         return (b*Hp + oy)*Wp + ox
     q0 = q_of(m0); qmax = B*Hp*Wp - 1
-    PROWS = 512
+    PROWS = 512 if BM == 256 else 768
+    PI = PROWS // 16 // 8
     for cc in range(Cin//32):
         # ---- patch image in LDS (bytes -> we store element ids per half element)
         lds = np.zeros((PROWS*32,), dtype=np.int64)   # 512 rows x 32 halves
         for wid in range(8):
-            for j in range(4):
+            for j in range(PI):
                 for lane in range(64):
-                    row = (wid*4 + j)*16 + (lane >> 2)
+                    row = (wid*PI + j)*16 + (lane >> 2)
                     c = (lane & 3) ^ swz(row)
                     q = min(q0 + row, qmax)
                     src = q*cstride + c*8 + cc*32          # element offset
-                    dst_byte = (wid*4 + j)*1024 + lane*16
+                    dst_byte = (wid*PI + j)*1024 + lane*16
                     lds[dst_byte//2: dst_byte//2 + 8] = x[src:src+8]
         # ---- fragment reads
-        for wm in range(8//NWN):
+        assert (BM // (32*TM)) * NWN == 8
+        for wm in range(BM // (32*TM)):
             for t in range(TM):
                 for lane in range(64):
                     frow, fhalf = lane & 31, lane >> 5
@@ -67,10 +69,13 @@ def conflicts(arows, shift):
             worst = max(worst, max(slots.values()))
     return worst
 
-@pytest.mark.parametrize("B,Ho,Cin,m0,TM,NWN", [(3, 40, 64, 0, 4, 4), (3, 40, 64, 1536, 4, 4), (3, 40, 64, 4608, 4, 4),
-                                                (5, 20, 64, 256, 4, 4), (5, 20, 64, 1792, 2, 2), (3, 24, 64, 512, 2, 2)])
-def test_conv_sw_patch_and_fragment_addressing(B, Ho, Cin, m0, TM, NWN):
-    assert run(B, Ho, Ho, Cin, m0, TM, NWN)
+# the two tile shapes of the kernel: 256 x 256 (TM 4, 4 wave columns) and 512 x 128 (TM 4, 2 wave columns, 768 patch rows)
+@pytest.mark.parametrize("B,Ho,Cin,m0,TM,NWN,BM", [(3, 40, 64, 0, 4, 4, 256), (3, 40, 64, 1536, 4, 4, 256), (3, 40, 64, 4608, 4, 4, 256),
+                                                   (5, 20, 64, 256, 4, 4, 256), (5, 20, 64, 1792, 4, 4, 256),
+                                                   (3, 40, 64, 0, 4, 2, 512), (3, 40, 64, 1536, 4, 2, 512), (3, 40, 64, 4608, 4, 2, 512),
+                                                   (3, 24, 64, 1536, 4, 2, 512), (6, 20, 64, 1024, 4, 2, 512)])
+def test_conv_sw_patch_and_fragment_addressing(B, Ho, Cin, m0, TM, NWN, BM):
+    assert run(B, Ho, Ho, Cin, m0, TM, NWN, BM=BM)
 
 
 def test_conv_sw_fragment_reads_are_bank_conflict_free():

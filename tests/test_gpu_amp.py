@@ -35,8 +35,21 @@ def _write_report():
     if REPORT:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_amp.json"), "w") as f:
-            json.dump(REPORT, f, indent=1, sort_keys=True)
+        path = os.path.join(out, "parity_amp.json")
+        merged = {}
+        if os.path.exists(path):          # several pytest invocations (-k subsets) contribute to one report
+            try:
+                with open(path) as f:
+                    merged = json.load(f)
+            except Exception:
+                merged = {}
+        for k, v in REPORT.items():
+            if isinstance(v, dict) and isinstance(merged.get(k), dict):
+                merged[k].update(v)
+            else:
+                merged[k] = v
+        with open(path, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
 
 
 def _padded_nhwc(x_nchw, pad, dev):
@@ -63,29 +76,29 @@ def test_conv7x7_policy(dev, bn, bias):
     w = r16(torch.randn((64, 6, 7, 7), generator=g) * 0.06 + torch.arange(64)[:, None, None, None] * 1e-4)
     b = r16(torch.randn(64, generator=g) * 0.2) if bias else None
     sb = _bn(g, 64) if bn else None
-    ref, mag = conv_amp_ref(x, w, b, sb, 2)
+    ref, mag, slack = conv_amp_ref(x, w, b, sb, 2)
     D = lambda t: None if t is None else t.to(dev)
     for pad in (1, 0):
         buf = torch.full((5, 80 + 2 * pad, 80 + 2 * pad, 64), 7.0, dtype=torch.float16, device=dev)
         ops.conv7x7s2_bn_relu(x.half().to(dev), w.half().reshape(64, -1).contiguous().to(dev), D(b), D(sb[0]) if bn else None,
                               D(sb[1]) if bn else None, buf, pad)
         out = buf[:, pad:pad + 80, pad:pad + 80].permute(0, 3, 1, 2).float().cpu()
-        assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.01, max_ulps=3, what=f"conv1 pad={pad}")
+        assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.01, max_ulps=2, what=f"conv1 pad={pad}", slack=slack.numpy())
         if pad:   # the border belongs to the caller
             assert float((buf[:, 0] - 7).abs().max()) == 0 and float((buf[:, -1] - 7).abs().max()) == 0
             assert float((buf[:, :, 0] - 7).abs().max()) == 0 and float((buf[:, :, -1] - 7).abs().max()) == 0
     # ragged shapes: odd number of bands, width not a multiple of 32 pixels per tile
     x2 = r16(torch.rand((3, 6, 104, 88), generator=g) * 2 - 1)
-    ref2, mag2 = conv_amp_ref(x2, w, b, sb, 2)
+    ref2, mag2, slack2 = conv_amp_ref(x2, w, b, sb, 2)
     buf = torch.zeros((3, 52, 44, 64), dtype=torch.float16, device=dev)
     ops.conv7x7s2_bn_relu(x2.half().to(dev), w.half().reshape(64, -1).contiguous().to(dev), D(b), D(sb[0]) if bn else None,
                           D(sb[1]) if bn else None, buf, 0)
-    assert_equal_up_to_flips(buf.permute(0, 3, 1, 2).float().cpu().numpy(), ref2.numpy(), mag2.numpy(), max_frac=0.01, max_ulps=3,
-                             what="conv1 ragged")
+    assert_equal_up_to_flips(buf.permute(0, 3, 1, 2).float().cpu().numpy(), ref2.numpy(), mag2.numpy(), max_frac=0.01, max_ulps=2,
+                             what="conv1 ragged", slack=slack2.numpy())
 
 
-# (B, H, Cin, Cout, stride, residual, bn): stride-1 shapes with B*H*H >= 512 run the shifted-window kernel
-# (conv_sw.hip: N = 128 -> 256x128 tile, N % 256 == 0 -> 256x256), the others the generic implicit GEMM
+# (B, H, Cin, Cout, stride, residual, bn): stride-1 shapes with at least two tiles of rows run the shifted-window kernel
+# (conv_sw.hip: N % 256 == 0 -> 256x256 tile, otherwise 512x128), the others the generic implicit GEMM
 @pytest.mark.parametrize("B,H,Cin,Cout,stride,res,bn", [
     (3, 40, 128, 128, 1, True, True), (2, 40, 256, 256, 1, True, True), (5, 20, 512, 512, 1, True, False),
     (7, 20, 512, 512, 1, False, True), (3, 24, 64, 384, 1, False, True), (1, 20, 256, 256, 1, True, True),
@@ -99,7 +112,7 @@ def test_igemm_conv3x3_policy(dev, B, H, Cin, Cout, stride, res, bn):
     sb = _bn(g, Cout) if bn else None
     Ho = H // stride
     r = r16(torch.randn((B, Cout, Ho, Ho), generator=g) * 0.5) if res else None
-    ref, mag = conv_amp_ref(x, w, bias, sb, stride, residual=r)
+    ref, mag, slack = conv_amp_ref(x, w, bias, sb, stride, residual=r)
     xb = _padded_nhwc(x.half(), 1, dev)
     wk = w.half().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dev)
     y = torch.zeros((B, Ho + 2, Ho + 2, Cout), dtype=torch.float16, device=dev)
@@ -110,7 +123,7 @@ def test_igemm_conv3x3_policy(dev, B, H, Cin, Cout, stride, res, bn):
     ops.igemm_f16(xb, gin, wk, bias.to(dev), y, gout, B * Ho * Ho, Cout, Cin, 9, relu=True, residual=rb, r_geom=gout if res else None,
                   bn_scale=sb[0].to(dev) if bn else None, bn_shift=sb[1].to(dev) if bn else None, conv_rounding=True)
     out = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
-    rep = assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.03, max_ulps=3, what="conv3x3")
+    rep = assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.03, max_ulps=2, what="conv3x3", slack=slack.numpy())
     REPORT.setdefault("kernel_flip_rates", {})[f"conv3x3 B{B} H{H} {Cin}->{Cout} s{stride}"] = rep
     assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0   # the zero border is left untouched
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
@@ -124,24 +137,27 @@ def test_igemm_channel_concat_and_linear_policy(dev):
     n, H, Cc = 3, 16, 128
     x = r16(torch.randn((2 * n, Cc, H, H), generator=g) * 0.5)
     w = r16(torch.randn((Cc, Cc, 3, 3), generator=g) * 0.03)
-    ref, mag = conv_amp_ref(x, w, None, None, 1, relu=False)
-    ref, mag = torch.cat([ref[:n], ref[n:]], dim=1), torch.cat([mag[:n], mag[n:]], dim=1)
+    ref, mag, slack = conv_amp_ref(x, w, None, None, 1, relu=False)
+    ref, mag, slack = (torch.cat([t[:n], t[n:]], dim=1) for t in (ref, mag, slack))
     y = torch.zeros((n, H + 2, H + 2, 2 * Cc), dtype=torch.float16, device=dev)
     gin = ops.IgemmGeom.image(H, H, 1, Cc, offset=0)
     gout = ops.IgemmGeom.image(H, H, 1, 2 * Cc, bsplit=n, cgroup=Cc)
     ops.igemm_f16(_padded_nhwc(x.half(), 1, dev), gin, w.half().permute(0, 2, 3, 1).reshape(Cc, -1).contiguous().to(dev), None, y, gout,
                   2 * n * H * H, Cc, Cc, 9, conv_rounding=True)
-    assert_equal_up_to_flips(y[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu().numpy(), ref.numpy(), mag.numpy(), what="bsplit")
+    assert_equal_up_to_flips(y[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu().numpy(), ref.numpy(), mag.numpy(), what="bsplit",
+                             slack=slack.numpy())
     for M, K, N, relu in ((1000, 512, 1536, False), (37, 64, 128, True), (4097, 512, 512, True), (252, 512, 1536, False)):
         xm = r16(torch.randn((M, K), generator=g))
         wm = r16(torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-4)   # asymmetric: a transposed fragment cannot pass
         b = r16(torch.randn(N, generator=g))
-        acc = xm @ wm.t() + b
+        acc = (xm.double() @ wm.double().t() + b.double()).float()
+        slack = (1e-6 * (xm.double().abs() @ wm.double().abs().t())).float()
         refm = r16(acc)
         refm = F.relu(refm) if relu else refm
         ym = torch.empty((M, N), dtype=torch.float16, device=dev)
         ops.igemm_f16(xm.half().to(dev), ops.IgemmGeom.matrix(K), wm.half().to(dev), b.to(dev), ym, ops.IgemmGeom.matrix(N), M, N, K, 1, relu=relu)
-        assert_equal_up_to_flips(ym.float().cpu().numpy(), refm.numpy(), acc.abs().numpy(), max_frac=0.02, what=f"linear {M}x{K}x{N}")
+        assert_equal_up_to_flips(ym.float().cpu().numpy(), refm.numpy(), acc.abs().numpy(), max_frac=0.02, what=f"linear {M}x{K}x{N}",
+                                 slack=slack.numpy())
 
 
 def test_rowops_policy(dev):
@@ -179,14 +195,15 @@ def test_rowops_policy(dev):
         x = torch.randn((M, K), generator=g)
         w = r16(torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-3)
         b = r16(torch.randn(N, generator=g))
-        ref = x @ w.t() + b
+        ref = (x.double() @ w.double().t() + b.double()).float()
+        slack = (1e-6 * (x.double().abs() @ w.double().abs().t())).float().numpy()
         y = ops.rows_linear(D(x), D(w.half()), D(b))
         np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=2e-5)
         yr = ops.rows_linear(D(x), D(w.half()), D(b), round_f16=True)
-        assert_equal_up_to_flips(yr.cpu().numpy(), r16(ref).numpy(), max_frac=0.02, what="rows_linear round")
+        assert_equal_up_to_flips(yr.cpu().numpy(), r16(ref).numpy(), max_frac=0.02, what="rows_linear round", slack=slack)
         yh = ops.rows_linear(D(x), D(w.half()), D(b), out_f16=True)
         assert yh.dtype == torch.float16 and torch.equal(yh.float(), yr)
-        ref16 = r16(x) @ w.t() + b
+        ref16 = (r16(x).double() @ w.double().t() + b.double()).float()
         y16 = ops.rows_linear(D(x.half()), D(w.half()), D(b))
         np.testing.assert_allclose(y16.cpu().numpy(), ref16.numpy(), atol=2e-5, rtol=2e-5)
 
