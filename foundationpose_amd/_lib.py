@@ -29,7 +29,7 @@ SIGNATURES = {
     "fp_warp_crops": (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, ci, ci, vp, vp]),
     "fp_pose_update": (ci, [vp, vp, vp, ci, ci, vp, cf, cf, ci, vp, vp, vp, ci, vp, vp, cf, vp]),
     "fp_conv7x7s2_bn_relu_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
-    "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
+    "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "fp_add_pe_f16_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "fp_layernorm_res_fwd": (ci, [vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, ci, ci, vp]),
     "fp_colmean_f16_fwd": (ci, [vp, vp, vp, vp, cf, vp, ci, ci, ci, vp]),

@@ -88,17 +88,20 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
     wf[ks][7] = (_Float16)0.f;
   }
   // bias / BN scale / shift of this lane's 16 output channels: channel = hsel*32 + 8*g4 + 4*kh + e
-  float bi[4][4], sc[4][4], sh[4][4];
+  typedef _Float16 half2b_ __attribute__((ext_vector_type(2)));
+  half2b_ bi2[4][2];
+  float sc[4][4], sh[4][4];
   const bool has_bn = p.scale != nullptr;
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4)
+  for (int g4 = 0; g4 < 4; ++g4) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int chn = hsel * 32 + 8 * g4 + 4 * kh + e;
-      bi[g4][e] = p.bias ? p.bias[chn] : 0.f;
+      bi2[g4][e >> 1][e & 1] = (_Float16)(p.bias ? p.bias[chn] : 0.f);
       sc[g4][e] = has_bn ? p.scale[chn] : 1.f;
       sh[g4][e] = has_bn ? p.shift[chn] : 0.f;
     }
+  }
 
   const int band_px = C1_ROWS * p.Wout;
   const int tiles = (band_px + 31) >> 5;
@@ -144,14 +147,23 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
       //      nn.Conv2d / nn.BatchNorm2d / nn.ReLU), transpose through the wave-private tile (32 px x 64 B), 16-byte stores
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
+        // packed fp16 math where it is exact (see igemm_epilogue.h): conv -> fp16, + bias as an IEEE half add, BatchNorm
+        // as an fp32 FMA rounded to fp16, ReLU on the packed halves
+        typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+        half2_ t01 = {(_Float16)acc[g4 * 4 + 0], (_Float16)acc[g4 * 4 + 1]};
+        half2_ t23 = {(_Float16)acc[g4 * 4 + 2], (_Float16)acc[g4 * 4 + 3]};
+        t01 = t01 + bi2[g4][0];
+        t23 = t23 + bi2[g4][1];
         half4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = (float)(_Float16)acc[g4 * 4 + e];
-          t = (float)(_Float16)(t + bi[g4][e]);
-          if (has_bn) t = (float)(_Float16)fmaf(t, sc[g4][e], sh[g4][e]);
-          v[e] = (_Float16)fmaxf(t, 0.f);
+        if (has_bn) {
+          v[0] = (_Float16)fmaf((float)t01[0], sc[g4][0], sh[g4][0]);
+          v[1] = (_Float16)fmaf((float)t01[1], sc[g4][1], sh[g4][1]);
+          v[2] = (_Float16)fmaf((float)t23[0], sc[g4][2], sh[g4][2]);
+          v[3] = (_Float16)fmaf((float)t23[1], sc[g4][3], sh[g4][3]);
+        } else {
+          v[0] = t01[0]; v[1] = t01[1]; v[2] = t23[0]; v[3] = t23[1];
         }
+        v = __builtin_elementwise_max(v, half4{0, 0, 0, 0});
         const int chl = 8 * g4 + 4 * kh;                 // channel within this wave's 32
         const int chunk = (chl >> 3) ^ (px & 3);
         *reinterpret_cast<half4*>(etile + px * 64 + (chunk << 4) + ((chl & 4) << 1)) = v;

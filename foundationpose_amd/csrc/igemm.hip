@@ -223,31 +223,33 @@ static IgemmGeom ig_geom(const fp_igemm_geom* g) {
   return o;
 }
 
-extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, const void* w, const float* bias,
-                                const float* bn_scale, const float* bn_shift, const void* residual,
-                                const fp_igemm_geom* r_geom, void* y, const fp_igemm_geom* y_geom, int M, int N, int Cin,
-                                int taps, int flags, void* stream) {
+extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, const void* w, void* y, const fp_igemm_geom* y_geom,
+                                int M, int N, int Cin, int taps, const fp_igemm_epilogue* ep, void* stream) {
   FP_REQUIRE(M >= 0, "fp_igemm_f16_fwd: M < 0");
   if (M == 0) return FP_OK;
   FP_REQUIRE(x && w && y && x_geom && y_geom, "fp_igemm_f16_fwd: NULL tensor / geometry");
   FP_REQUIRE(taps == 1 || taps == 9, "fp_igemm_f16_fwd: taps must be 1 (GEMM) or 9 (3x3 conv), got %d", taps);
   FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
   FP_REQUIRE(Cin > 0 && Cin % 64 == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of 64", Cin);
-  FP_REQUIRE(!residual || r_geom, "fp_igemm_f16_fwd: residual without geometry");
-  FP_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fp_igemm_f16_fwd: bn_scale and bn_shift go together");
-  FP_REQUIRE(!bn_scale || (flags & FP_IGEMM_ROUND_ACC), "fp_igemm_f16_fwd: BatchNorm needs FP_IGEMM_ROUND_ACC (conv semantics)");
-  FP_REQUIRE((flags & ~(FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC)) == 0, "fp_igemm_f16_fwd: unknown flags 0x%x", flags);
-  FP_REQUIRE((((size_t)x | (size_t)w | (size_t)y | (size_t)residual | (size_t)bias | (size_t)bn_scale | (size_t)bn_shift) & 15) == 0,
-             "fp_igemm_f16_fwd: tensors must be 16-byte aligned");
-  if (int e = ig_check_geom(x_geom, "input")) return e;
-  if (int e = ig_check_geom(y_geom, "output")) return e;
-  if (residual) if (int e = ig_check_geom(r_geom, "residual")) return e;
+  static const fp_igemm_epilogue no_epilogue = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr};
+  const fp_igemm_epilogue& e = ep ? *ep : no_epilogue;
+  FP_REQUIRE(!e.residual || e.r_geom, "fp_igemm_f16_fwd: residual without geometry");
+  FP_REQUIRE((e.bn_scale == nullptr) == (e.bn_shift == nullptr), "fp_igemm_f16_fwd: bn_scale and bn_shift go together");
+  FP_REQUIRE(!e.bn_scale || (e.flags & FP_IGEMM_ROUND_ACC), "fp_igemm_f16_fwd: BatchNorm needs FP_IGEMM_ROUND_ACC (conv semantics)");
+  FP_REQUIRE((e.flags & ~(FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC)) == 0, "fp_igemm_f16_fwd: unknown flags 0x%x", e.flags);
+  FP_REQUIRE((e.pe == nullptr) == (e.y_pe == nullptr) && (!e.pe || e.pe_period > 0), "fp_igemm_f16_fwd: pe, pe_period and y_pe go together");
+  FP_REQUIRE((((size_t)x | (size_t)w | (size_t)y | (size_t)e.residual | (size_t)e.bias | (size_t)e.bn_scale | (size_t)e.bn_shift |
+               (size_t)e.pe | (size_t)e.y_pe) & 15) == 0, "fp_igemm_f16_fwd: tensors must be 16-byte aligned");
+  if (int err = ig_check_geom(x_geom, "input")) return err;
+  if (int err = ig_check_geom(y_geom, "output")) return err;
+  if (e.residual) if (int err = ig_check_geom(e.r_geom, "residual")) return err;
   IgemmParams p;
-  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
-  p.R = (const _Float16*)residual; p.Y = (_Float16*)y;
-  p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = (flags & FP_IGEMM_RELU) ? 1 : 0;
-  p.round_acc = (flags & FP_IGEMM_ROUND_ACC) ? 1 : 0;
-  p.in = ig_geom(x_geom); p.out = ig_geom(y_geom); p.res = residual ? ig_geom(r_geom) : ig_geom(y_geom);
+  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = e.bias; p.bn_scale = e.bn_scale; p.bn_shift = e.bn_shift;
+  p.R = (const _Float16*)e.residual; p.Y = (_Float16*)y;
+  p.pe = e.pe; p.Ype = (_Float16*)e.y_pe; p.pe_period = e.pe_period;
+  p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = (e.flags & FP_IGEMM_RELU) ? 1 : 0;
+  p.round_acc = (e.flags & FP_IGEMM_ROUND_ACC) ? 1 : 0;
+  p.in = ig_geom(x_geom); p.out = ig_geom(y_geom); p.res = e.residual ? ig_geom(e.r_geom) : ig_geom(y_geom);
   int sel = 0;
 #ifdef FP_PROFILE_BUILD
   // profiling builds only (make PROFILE=1): FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | pp256x256 | pp256x128 | generic

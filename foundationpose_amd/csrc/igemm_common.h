@@ -45,6 +45,9 @@ struct IgemmParams {
   const float* bn_shift;
   const _Float16* R;    // residual or null
   _Float16* Y;
+  const float* pe;      // optional second output (the positional-embedding add of network_modules.py:133-137 fused into the
+  _Float16* Ype;        // last conv): Ype[m][n] = f16(f32(y[m][n]) + pe[m % pe_period][n]), a plain (M, N) matrix
+  int pe_period;
   int M, N, Cin, taps;
   int relu;
   int round_acc;        // FP_IGEMM_ROUND_ACC: the accumulator is rounded to fp16 BEFORE the bias is added (nn.Conv2d under

@@ -68,13 +68,23 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
         const int ml = wm * (32 * TM) + j * 32 + (lane & 31);
         half4 v;
         if (round_acc) {
-          // the reference's autocast op sequence for conv (+ BatchNorm): every op rounds its result to fp16
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = (float)(_Float16)acc[i][j][g * 4 + e];
-            t = (float)(_Float16)(t + bv[e]);
-            if (has_bn) t = fmaf(t, sc[e], sh[e]);
-            v[e] = (_Float16)t;
+          // the reference's autocast op sequence for conv (+ BatchNorm): every op rounds its result to fp16.  Packed
+          // fp16 math where it is exact: v_cvt_pk_f16_f32 for the conv output, v_pk_add_f16 for the bias (an IEEE half
+          // add of two halves equals their fp32 sum rounded to half: when the fp32 sum is inexact the smaller addend is
+          // below 1/8 ulp of the larger), fp32 FMA for BatchNorm (fp32 statistics)
+          typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+          const half2_ b01 = {(_Float16)bv[0], (_Float16)bv[1]}, b23 = {(_Float16)bv[2], (_Float16)bv[3]};
+          half2_ t01 = {(_Float16)acc[i][j][g * 4 + 0], (_Float16)acc[i][j][g * 4 + 1]};
+          half2_ t23 = {(_Float16)acc[i][j][g * 4 + 2], (_Float16)acc[i][j][g * 4 + 3]};
+          t01 = t01 + b01;
+          t23 = t23 + b23;
+          if (has_bn) {
+            v[0] = (_Float16)fmaf((float)t01[0], sc[0], sh[0]);
+            v[1] = (_Float16)fmaf((float)t01[1], sc[1], sh[1]);
+            v[2] = (_Float16)fmaf((float)t23[0], sc[2], sh[2]);
+            v[3] = (_Float16)fmaf((float)t23[1], sc[3], sh[3]);
+          } else {
+            v[0] = t01[0]; v[1] = t01[1]; v[2] = t23[0]; v[3] = t23[1];
           }
         } else {
 #pragma unroll
@@ -97,6 +107,15 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
     if (p.R) v = v + rv[it];                       // IEEE half add == the fp32 add of two halves rounded once
     if (p.relu) v = __builtin_elementwise_max(v, zero);
     *reinterpret_cast<half8*>(p.Y + yo + ch * 8) = v;
+    if (p.Ype) {                                   // tokens + positional table, rounded for the in_proj GEMM
+      const int m = m0 + ml;
+      const float* per = p.pe + (size_t)(m % p.pe_period) * p.N + n0 + ch * 8;
+      const float4_ e0 = *reinterpret_cast<const float4_*>(per), e1 = *reinterpret_cast<const float4_*>(per + 4);
+      half8 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w[e] = (_Float16)((float)v[e] + e0[e]); w[4 + e] = (_Float16)((float)v[4 + e] + e1[e]); }
+      *reinterpret_cast<half8*>(p.Ype + (size_t)m * p.N + n0 + ch * 8) = w;
+    }
   }
 }
 

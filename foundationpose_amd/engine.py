@@ -8,7 +8,8 @@ by rounding point (the restatement the tests check against is oracle/nets_amp.py
   * the 15 3x3 convs: fp16(conv) + bias -> fp16, BatchNorm -> fp16, (+ identity -> fp16), ReLU
                                                                 -> fp_igemm_f16_fwd (FP_IGEMM_ROUND_ACC)
   * positional table: fp16 tokens + fp32 table = the fp32 residual stream; its fp16 rounding feeds in_proj
-                                                                -> fp_add_pe_f16_fwd (the fp32 sum is recomputed by the LayerNorm)
+                                                                -> second output of the last conv's epilogue (fp_igemm_epilogue.pe;
+                                                                   the fp32 sum itself is recomputed by the LayerNorm)
   * every 512-wide Linear (in_proj, out_proj, linear1, linear2): one rounding of accumulator + bias
                                                                 -> fp_igemm_f16_fwd
   * self-attention between in_proj and out_proj                  -> fp_attention_f16_fwd (flash order = F.scaled_dot_product_
@@ -185,7 +186,7 @@ class _HipEncoder:
             self._bufs[key] = b
         return b
 
-    def _conv(self, name, x, Bn, Ho, Wo, Cin, Cout, y, stride=1, res=None, relu=True, gout=None, gres=None):
+    def _conv(self, name, x, Bn, Ho, Wo, Cin, Cout, y, stride=1, res=None, relu=True, gout=None, gres=None, pe=None, y_pe=None):
         c = self.w[name]
         G = ops.IgemmGeom.image
         gin = G(Ho, Wo, 1, Cin, stride=stride, offset=0)
@@ -193,10 +194,11 @@ class _HipEncoder:
         if res is not None and gres is None:
             gres = G(Ho, Wo, 1, Cout)
         return ops.igemm_f16(x, gin, c["w"], c["bias"], y, gout, Bn * Ho * Wo, Cout, Cin, 9, relu=relu, residual=res, r_geom=gres,
-                             bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True)
+                             bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True, pe=pe, y_pe=y_pe)
 
     def __call__(self, AB):
-        """AB (2n,6,H,W) fp16 -> tokens (n, H/8 * W/8, 512) fp16 (before the positional table)"""
+        """AB (2n,6,H,W) fp16 -> (tokens (n, H/8 * W/8, 512) fp16 before the positional table,
+        x16 = f16(f32(tokens) + pe): the in_proj operand, written by the same epilogue)"""
         n2, _, H, W = AB.shape
         n = n2 // 2
         b = self._buffers(n, H, W)
@@ -219,8 +221,10 @@ class _HipEncoder:
         self._conv("j3b", b["T3"], n, h3, w3, 512, 512, b["Q1"], res=b["Q0"])
         self._conv("j4a", b["Q1"], n, h3, w3, 512, 512, b["T3"])
         tok = torch.empty((n, h3 * w3, 512), dtype=torch.float16, device=AB.device)
-        self._conv("j4b", b["T3"], n, h3, w3, 512, 512, tok, res=b["Q1"], gout=G(h3, w3, 0, 512), gres=G(h3, w3, 1, 512))
-        return tok
+        x16 = torch.empty_like(tok)
+        self._conv("j4b", b["T3"], n, h3, w3, 512, 512, tok, res=b["Q1"], gout=G(h3, w3, 0, 512), gres=G(h3, w3, 1, 512),
+                   pe=self.pe[: h3 * w3], y_pe=x16)
+        return tok, x16
 
 
 class _HipLinear:
@@ -314,8 +318,7 @@ class RefinePlan:
         """AB (2N,6,H,W) in the plan's dtype -> {'trans': (N,3) f32, 'rot': (N,3|6) f32}"""
         out = {}
         if self.hip:
-            tok16 = self.enc(AB)
-            x16 = ops.add_pe_f16(tok16, self.enc.pe)
+            tok16, x16 = self.enc(AB)
             for name, (layer, head) in self.heads.items():
                 # Linear and the token mean commute: mean_t(x_t W^T + b) = (mean_t x_t) W^T + b, so the 512 -> 3|6 head
                 # runs on N rows instead of N*400 (refine_network.py:90-91); the result is held in fp16 by the reference
@@ -347,8 +350,7 @@ class ScorePlan:
     def features(self, AB):
         """(2n,6,H,W) -> pooled per-hypothesis features (n,512), fp16 on the HIP plan (score_network.py:60-74)"""
         if self.hip:
-            tok16 = self.enc(AB)
-            x16 = ops.add_pe_f16(tok16, self.enc.pe)
+            _, x16 = self.enc(AB)
             # out_proj and the token mean commute (score_network.py:73-74): pool the attention output, project N rows
             return self.att.out_rows(ops.colmean_f16(self.att.context(x16)), out_f16=True)
         return self.att(self.enc(AB)).float().mean(dim=1)

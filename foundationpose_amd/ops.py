@@ -280,19 +280,30 @@ IGEMM_RELU = 1
 IGEMM_ROUND_ACC = 2
 
 
+class IgemmEpilogue(C.Structure):
+    """fp_igemm_epilogue (include/fp_amd.h)"""
+    _fields_ = [("bias", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("residual", C.c_void_p),
+                ("r_geom", C.POINTER(IgemmGeom)), ("flags", C.c_int), ("pe", C.c_void_p), ("pe_period", C.c_int), ("y_pe", C.c_void_p)]
+
+
 def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None, bn_scale=None,
-              bn_shift=None, conv_rounding=False):
+              bn_shift=None, conv_rounding=False, pe=None, y_pe=None):
     """y = act(f16(epilogue(implicit_gemm(x, w))) (+ residual)) -- see fp_igemm_f16_fwd.  conv_rounding: nn.Conv2d under
     autocast (accumulator rounded to fp16 before the bias add, optional BatchNorm as scale/shift with its own rounding);
-    otherwise nn.Linear (one rounding of accumulator + bias).  All tensors are device buffers owned by the caller (y is
-    written in place and returned)."""
+    otherwise nn.Linear (one rounding of accumulator + bias).  pe (S, N) f32 + y_pe (M, N) fp16: second output
+    f16(f32(y) + pe[m % S]).  All tensors are device buffers owned by the caller (y is written in place and returned)."""
     x = _dev(x, torch.float16, "x"); w = _dev(w, torch.float16, "w"); y = _dev(y, torch.float16, "y")
     b = _dev(bias, torch.float32, "bias"); r = _dev(residual, torch.float16, "residual")
     sc = _dev(bn_scale, torch.float32, "bn_scale"); sh = _dev(bn_shift, torch.float32, "bn_shift")
-    flags = (IGEMM_RELU if relu else 0) | (IGEMM_ROUND_ACC if conv_rounding else 0)
-    st = _lib.lib().fp_igemm_f16_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), _ptr(r),
-                                     C.byref(r_geom) if r_geom is not None else None, _ptr(y), C.byref(y_geom), int(M), int(N),
-                                     int(Cin), int(taps), flags, _stream(x))
+    pe = _dev(pe, torch.float32, "pe"); y_pe = _dev(y_pe, torch.float16, "y_pe")
+    ep = IgemmEpilogue()
+    ep.bias, ep.bn_scale, ep.bn_shift = _ptr(b), _ptr(sc), _ptr(sh)
+    ep.residual = _ptr(r)
+    ep.r_geom = C.pointer(r_geom) if r_geom is not None else None
+    ep.flags = (IGEMM_RELU if relu else 0) | (IGEMM_ROUND_ACC if conv_rounding else 0)
+    ep.pe, ep.pe_period, ep.y_pe = _ptr(pe), (int(pe.shape[-2]) if pe is not None else 0), _ptr(y_pe)
+    st = _lib.lib().fp_igemm_f16_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(y), C.byref(y_geom), int(M), int(N), int(Cin),
+                                     int(taps), C.byref(ep), _stream(x))
     _lib.check(st, "fp_igemm_f16_fwd")
     return y
 

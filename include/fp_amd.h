@@ -146,17 +146,30 @@ typedef struct {
                                 bias to the fp16 convolution output) and BatchNorm, if given, rounds once more; without the
                                 flag: nn.Linear semantics, one rounding of accumulator + bias */
 
+/* What fp_igemm_f16_fwd does with the fp32 accumulators (all members optional; NULL struct = plain fp16 store) */
+typedef struct {
+  const float* bias;           /* dev (N) f32 | NULL; for conv semantics fp16-representable values */
+  const float* bn_scale;       /* dev (N) f32 | NULL: eval BatchNorm2d as x*scale + shift (needs FP_IGEMM_ROUND_ACC) */
+  const float* bn_shift;
+  const void* residual;        /* dev fp16 | NULL: `out += identity` (network_modules.py:107), rounded to fp16 */
+  const fp_igemm_geom* r_geom; /* host: addressing of the residual */
+  int flags;                   /* FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC */
+  const float* pe;             /* dev (pe_period, N) f32 | NULL: second output y_pe[m, n] = f16(f32(y[m, n]) + pe[m % pe_period, n]), */
+  int pe_period;               /*   the PositionalEmbedding add of network_modules.py:133-137 fused into the last conv of the */
+  void* y_pe;                  /*   encoder; y_pe is a plain (M, N) fp16 matrix */
+} fp_igemm_epilogue;
+
 /* network_modules.py:37-50 ConvBNReLU / :73-111 ResnetBasicBlock (3x3, pad 1, stride 1|2, eval BatchNorm) and the
  * 512-wide Linear layers of refine_network.py:56-70 / score_network.py:52-53, as ONE MFMA implicit GEMM:
  *   acc[m, n] = sum_{tap, ci} x[row(m) + tap][ci] * w[n][tap*Cin + ci]                       (fp32 accumulation)
- *   y = act( f16(epilogue(acc)) (+ residual[m, n], rounded to f16) ),  epilogue per the flags above.
+ *   y = act( f16(epilogue(acc)) (+ residual[m, n], rounded to f16) ),  epilogue per fp_igemm_epilogue.
  * x / y / residual: NHWC fp16 addressed by their fp_igemm_geom (the input's border must be zero; its geometry
- * addresses tap (0,0), i.e. offset = 0 for pad 1); w (N, taps*Cin) fp16 with k ordered (ky, kx, ci); bias, bn_scale,
- * bn_shift (N) f32.  taps = 9 (3x3) or 1 (GEMM); N % 128 == 0; Cin % 64 == 0. */
-int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/,
-                     const float* bias /*dev|NULL*/, const float* bn_scale /*dev|NULL*/, const float* bn_shift /*dev|NULL*/,
-                     const void* residual /*dev|NULL*/, const fp_igemm_geom* r_geom /*host|NULL*/, void* y /*dev*/,
-                     const fp_igemm_geom* y_geom /*host*/, int M, int N, int Cin, int taps, int flags, void* stream);
+ * addresses tap (0,0), i.e. offset = 0 for pad 1); w (N, taps*Cin) fp16 with k ordered (ky, kx, ci).
+ * taps = 9 (3x3) or 1 (GEMM); N % 128 == 0; Cin % 64 == 0.  Stride-1 3x3 convolutions over one padded grid run the
+ * shifted-window kernel (csrc/conv_sw.hip), everything else the generic implicit GEMM. */
+int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/, void* y /*dev*/,
+                     const fp_igemm_geom* y_geom /*host*/, int M, int N, int Cin, int taps,
+                     const fp_igemm_epilogue* epilogue /*host|NULL*/, void* stream);
 
 /* network_modules.py:133-137 PositionalEmbedding as the in_proj operand: out = f16(f32(tok) + pe[row % S]).
  * tok / out (M, D) fp16, pe (S, D) f32; D must be 512.  (The fp32 sum itself is never stored: fp_layernorm_res_fwd

@@ -38,14 +38,21 @@ def test_argument_errors_are_reported_without_gpu():
     assert lib.fp_workspace_bytes(0, 2501, 4900, 160, 160) == 0
     big = lib.fp_workspace_bytes(4, 100000, 200000, 160, 160)        # > 65535 triangles: 32-bit ids in the lists
     assert big >= 4 * (100000 * 32 + 10 * 200000 * 4)
-    # GEMM geometry errors
+    # GEMM geometry / epilogue errors
+    from foundationpose_amd.ops import IgemmEpilogue
     G = (C.c_int * 10)(1, 1, 1, 1, 1, 0, 512, 0, 0, 0)
-    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), None, None, None, None, None, C.c_void_p(16), G, 4, 100, 512, 1, 0, None) == -1
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 100, 512, 1, None, None) == -1
     assert b"multiple of 128" in lib.fp_last_error()
-    # BatchNorm in the epilogue only with the conv rounding sequence; unknown flags are refused
-    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), None, C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), G, 4, 128, 512, 1, 1, None) == -1
+    ep = IgemmEpilogue()
+    ep.bn_scale, ep.bn_shift, ep.flags = 16, 16, 1      # BatchNorm in the epilogue only with the conv rounding sequence
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, C.byref(ep), None) == -1
     assert b"FP_IGEMM_ROUND_ACC" in lib.fp_last_error()
-    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), None, None, None, None, None, C.c_void_p(16), G, 4, 128, 512, 1, 8, None) == -1
+    ep = IgemmEpilogue()
+    ep.flags = 8                                        # unknown flags are refused
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, C.byref(ep), None) == -1
+    ep = IgemmEpilogue()
+    ep.pe = 16                                          # positional table without its output / period
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, C.byref(ep), None) == -1
     assert lib.fp_layernorm_res_fwd(None, C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,
                                     C.c_void_p(16), None, 4, 256, None) == -1
     assert lib.fp_layernorm_res_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,

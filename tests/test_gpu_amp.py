@@ -155,7 +155,11 @@ def test_igemm_channel_concat_and_linear_policy(dev):
         refm = r16(acc)
         refm = F.relu(refm) if relu else refm
         ym = torch.empty((M, N), dtype=torch.float16, device=dev)
-        ops.igemm_f16(xm.half().to(dev), ops.IgemmGeom.matrix(K), wm.half().to(dev), b.to(dev), ym, ops.IgemmGeom.matrix(N), M, N, K, 1, relu=relu)
+        pe = torch.randn((100, N), generator=g)           # second output: f16(f32(y) + pe[m % 100]) (the fused positional table)
+        ype = torch.empty((M, N), dtype=torch.float16, device=dev)
+        ops.igemm_f16(xm.half().to(dev), ops.IgemmGeom.matrix(K), wm.half().to(dev), b.to(dev), ym, ops.IgemmGeom.matrix(N), M, N, K, 1, relu=relu,
+                      pe=pe.to(dev), y_pe=ype)
+        assert torch.equal(ype.cpu(), (ym.float().cpu() + pe[torch.arange(M) % 100]).half()), "fused positional table"
         assert_equal_up_to_flips(ym.float().cpu().numpy(), refm.numpy(), acc.abs().numpy(), max_frac=0.02, what=f"linear {M}x{K}x{N}",
                                  slack=slack.numpy())
 
@@ -248,8 +252,10 @@ def test_hip_encoder_matches_amp_oracle(dev, use_bn):
     tr = {}
     nets_amp.encoder_tokens(AB[:n], AB[n:], sd, "encodeA", "encodeAB", tr)
     enc = engine._HipEncoder({k: v.to(dev) for k, v in sd.items()}, "encodeA", "encodeAB", dev)
-    hip = enc(AB.half().to(dev))
+    hip, x16 = enc(AB.half().to(dev))
     assert hip.shape == (n, 400, 512)
+    # the fused positional table: the in_proj operand is the fp16 rounding of fp16 tokens + fp32 table
+    assert torch.equal(x16.cpu(), (hip.float().cpu() + sd["pos_embed.pe"].float()[:, :400]).half())
     # first block: a 294-term reduction, compared on its own buffer (interior of the padded NHWC activation)
     c1 = enc._bufs[(n, 160, 160)]["P1"][:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu()
     r1 = flip_report(c1.numpy(), tr["conv1"].numpy())
@@ -257,7 +263,7 @@ def test_hip_encoder_matches_amp_oracle(dev, use_bn):
     REPORT.setdefault("encoder_vs_oracle", {})[f"bn{int(use_bn)}"] = dict(conv1=r1, tokens=rep)
     assert r1["frac"] < 0.01 and r1["max_abs"] <= 4 * ulp16(tr["conv1"].abs().max().item()), r1
     assert rep["rel_rms"] < 2e-3 and rep["max_abs"] <= 16 * ulp16(tr["tok16"].abs().max().item()), rep
-    assert torch.equal(hip, enc(AB.half().to(dev)))     # second call reuses the cached zero-bordered buffers
+    assert torch.equal(hip, enc(AB.half().to(dev))[0])     # second call reuses the cached zero-bordered buffers
 
 
 def test_plans_match_amp_oracle(dev):
