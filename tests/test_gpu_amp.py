@@ -83,7 +83,7 @@ def test_conv7x7_policy(dev, bn, bias):
         ops.conv7x7s2_bn_relu(x.half().to(dev), w.half().reshape(64, -1).contiguous().to(dev), D(b), D(sb[0]) if bn else None,
                               D(sb[1]) if bn else None, buf, pad)
         out = buf[:, pad:pad + 80, pad:pad + 80].permute(0, 3, 1, 2).float().cpu()
-        assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.01, max_ulps=2, what=f"conv1 pad={pad}", slack=slack.numpy())
+        assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.01, max_ulps=3.2 if bn else 1.0, what=f"conv1 pad={pad}", slack=slack.numpy())
         if pad:   # the border belongs to the caller
             assert float((buf[:, 0] - 7).abs().max()) == 0 and float((buf[:, -1] - 7).abs().max()) == 0
             assert float((buf[:, :, 0] - 7).abs().max()) == 0 and float((buf[:, :, -1] - 7).abs().max()) == 0
@@ -93,7 +93,7 @@ def test_conv7x7_policy(dev, bn, bias):
     buf = torch.zeros((3, 52, 44, 64), dtype=torch.float16, device=dev)
     ops.conv7x7s2_bn_relu(x2.half().to(dev), w.half().reshape(64, -1).contiguous().to(dev), D(b), D(sb[0]) if bn else None,
                           D(sb[1]) if bn else None, buf, 0)
-    assert_equal_up_to_flips(buf.permute(0, 3, 1, 2).float().cpu().numpy(), ref2.numpy(), mag2.numpy(), max_frac=0.01, max_ulps=2,
+    assert_equal_up_to_flips(buf.permute(0, 3, 1, 2).float().cpu().numpy(), ref2.numpy(), mag2.numpy(), max_frac=0.01, max_ulps=3.2 if bn else 1.0,
                              what="conv1 ragged", slack=slack2.numpy())
 
 
@@ -102,7 +102,9 @@ def test_conv7x7_policy(dev, bn, bias):
 @pytest.mark.parametrize("B,H,Cin,Cout,stride,res,bn", [
     (3, 40, 128, 128, 1, True, True), (2, 40, 256, 256, 1, True, True), (5, 20, 512, 512, 1, True, False),
     (7, 20, 512, 512, 1, False, True), (3, 24, 64, 384, 1, False, True), (1, 20, 256, 256, 1, True, True),
-    (2, 80, 64, 128, 2, False, True), (3, 40, 256, 512, 2, False, True), (1, 8, 128, 128, 1, True, True)])
+    (2, 80, 64, 128, 2, False, True), (3, 40, 256, 512, 2, False, True), (1, 8, 128, 128, 1, True, True),
+    # more tiles than CUs: whole rounds on the shifted-window kernel, the partial round on the 128x128 kernel (side stream)
+    (83, 40, 64, 128, 1, True, True)])
 def test_igemm_conv3x3_policy(dev, B, H, Cin, Cout, stride, res, bn):
     from foundationpose_amd import ops
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + H)
@@ -123,7 +125,9 @@ def test_igemm_conv3x3_policy(dev, B, H, Cin, Cout, stride, res, bn):
     ops.igemm_f16(xb, gin, wk, bias.to(dev), y, gout, B * Ho * Ho, Cout, Cin, 9, relu=True, residual=rb, r_geom=gout if res else None,
                   bn_scale=sb[0].to(dev) if bn else None, bn_shift=sb[1].to(dev) if bn else None, conv_rounding=True)
     out = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
-    rep = assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.03, max_ulps=2, what="conv3x3", slack=slack.numpy())
+    # a flip before BatchNorm is scaled by |scale| <= 2.1 on its way out
+    rep = assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.03, max_ulps=3.2 if bn else 1.0, what="conv3x3",
+                                   slack=slack.numpy())
     REPORT.setdefault("kernel_flip_rates", {})[f"conv3x3 B{B} H{H} {Cin}->{Cout} s{stride}"] = rep
     assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0   # the zero border is left untouched
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
@@ -146,7 +150,9 @@ def test_igemm_channel_concat_and_linear_policy(dev):
                   2 * n * H * H, Cc, Cc, 9, conv_rounding=True)
     assert_equal_up_to_flips(y[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu().numpy(), ref.numpy(), mag.numpy(), what="bsplit",
                              slack=slack.numpy())
-    for M, K, N, relu in ((1000, 512, 1536, False), (37, 64, 128, True), (4097, 512, 512, True), (252, 512, 1536, False)):
+    # (11264, 512, 1536): 264 tiles of 256x256 on 256 CUs -> split launch (whole round + remainder rows on the 128x128 kernel)
+    for M, K, N, relu in ((1000, 512, 1536, False), (37, 64, 128, True), (4097, 512, 512, True), (252, 512, 1536, False),
+                          (11264, 512, 1536, True)):
         xm = r16(torch.randn((M, K), generator=g))
         wm = r16(torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-4)   # asymmetric: a transposed fragment cannot pass
         b = r16(torch.randn(N, generator=g))
