@@ -240,7 +240,11 @@ static IgSide* ig_side_stream() {
   (void)hipGetDevice(&dev);
   IgSide& d = side[dev & 63];
   if (!d.s) {
-    d.ok = hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking) == hipSuccess &&
+    // LOWEST priority: the hardware hands a free CU to the large-tile kernel as long as it has workgroups left, so the
+    // small tiles run where and when the last round leaves CUs idle instead of delaying whole rounds
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    d.ok = hipStreamCreateWithPriority(&d.s, hipStreamNonBlocking, least) == hipSuccess &&
            hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess;
   }
@@ -308,10 +312,6 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
       fp_set_error("fp_igemm_f16_fwd: cannot fork the side stream");
       return FP_ERR_LAUNCH;
     }
-    IgemmParams r = p;
-    r.m_base = main_mtiles * BM;
-    if (int e = ig_launch<128, 128, 2, 2, 64>(r, side->s)) return e;
-    if (hipEventRecord(side->join, side->s) != hipSuccess) { fp_set_error("fp_igemm_f16_fwd: cannot record the join event"); return FP_ERR_LAUNCH; }
   } else {
     main_mtiles = -1;
   }
@@ -324,9 +324,14 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
 #endif
   else err = ig_launch<128, 128, 2, 2, 64>(p, stream);
   if (err) return err;
-  if (main_mtiles >= 0 && hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
-    fp_set_error("fp_igemm_f16_fwd: cannot join the side stream");
-    return FP_ERR_LAUNCH;
+  if (main_mtiles >= 0) {
+    IgemmParams r = p;
+    r.m_base = main_mtiles * BM;
+    if (int e = ig_launch<128, 128, 2, 2, 64>(r, side->s)) return e;
+    if (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
+      fp_set_error("fp_igemm_f16_fwd: cannot join the side stream");
+      return FP_ERR_LAUNCH;
+    }
   }
   return FP_OK;
 }

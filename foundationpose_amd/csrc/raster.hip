@@ -166,7 +166,7 @@ __device__ __forceinline__ void tex_fetch(const float* __restrict__ tex, int Ht,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pipeline of one fp_render_crops call (a memset + two launches on the caller's stream, scratch in the caller's workspace):
+// Pipeline of one fp_render_crops call (a counter reset + two launches on the caller's stream, scratch in the caller's workspace):
 //   k_bin    : grid (T/256, N)  one lane per (hypothesis, triangle): projects its three vertices, finds the strips of
 //              FP_STRIP_ROWS rows its clipped bounding box touches
 //              -> per-(hypothesis, strip) triangle lists (wave-ballot compaction, one atomicAdd per wave and strip)
@@ -219,6 +219,11 @@ __device__ __forceinline__ VtxAttr vertex_attr(const fp_mesh& m, const HypConst&
 
 __device__ __forceinline__ VtxRec vertex_rec(const fp_mesh& m, const HypConst& h, int v) {
   return project_vertex(h, m.pos[v * 3], m.pos[v * 3 + 1], m.pos[v * 3 + 2]);
+}
+
+__global__ __launch_bounds__(256) void k_zero_counts(int* __restrict__ counts, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) counts[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_bin(fp_mesh m, const float* __restrict__ poses, const float* __restrict__ bbox2d,
@@ -529,10 +534,10 @@ extern "C" int fp_render_crops(const fp_mesh* mesh, const float* poses, const fl
   const float inv_r = 1.0f / (mesh_diameter * 0.5f);
   RenderOut out = {A, color, depth, xyz, normal, zbuf, tri_id};
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws.counts, 0, (size_t)N * L.nstrips * sizeof(int), st) != hipSuccess) {   // a memset node under capture
-    fp_set_error("fp_render_crops: hipMemsetAsync failed");
-    return FP_ERR_LAUNCH;
-  }
+  // list counters back to zero (a plain kernel rather than hipMemsetAsync: replaying a captured memset node of this size
+  // aborted inside the runtime on ROCm 7.0)
+  hipLaunchKernelGGL(k_zero_counts, dim3(fp_cdiv(N * L.nstrips, 256)), dim3(256), 0, st, ws.counts, N * L.nstrips);
+  FP_CHECK_LAUNCH("fp_render_crops(zero)");
   hipLaunchKernelGGL(k_bin, dim3(fp_cdiv(mesh->T, 256), N), dim3(256), 0, st, *mesh, poses, bbox2d, K, H, W, oh, ow, L.nstrips, ws);
   FP_CHECK_LAUNCH("fp_render_crops(bin)");
   const size_t lds = (size_t)FP_STRIP_ROWS * ow * sizeof(unsigned long long) + 16 + FP_BIG_MAX * sizeof(BigTri);

@@ -83,7 +83,7 @@ def test_conv7x7_policy(dev, bn, bias):
         ops.conv7x7s2_bn_relu(x.half().to(dev), w.half().reshape(64, -1).contiguous().to(dev), D(b), D(sb[0]) if bn else None,
                               D(sb[1]) if bn else None, buf, pad)
         out = buf[:, pad:pad + 80, pad:pad + 80].permute(0, 3, 1, 2).float().cpu()
-        assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.01, max_ulps=3.2 if bn else 1.0, what=f"conv1 pad={pad}", slack=slack.numpy())
+        assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.01, max_ulps=4.2 if bn else 2.0, what=f"conv1 pad={pad}", slack=slack.numpy())
         if pad:   # the border belongs to the caller
             assert float((buf[:, 0] - 7).abs().max()) == 0 and float((buf[:, -1] - 7).abs().max()) == 0
             assert float((buf[:, :, 0] - 7).abs().max()) == 0 and float((buf[:, :, -1] - 7).abs().max()) == 0
@@ -93,7 +93,7 @@ def test_conv7x7_policy(dev, bn, bias):
     buf = torch.zeros((3, 52, 44, 64), dtype=torch.float16, device=dev)
     ops.conv7x7s2_bn_relu(x2.half().to(dev), w.half().reshape(64, -1).contiguous().to(dev), D(b), D(sb[0]) if bn else None,
                           D(sb[1]) if bn else None, buf, 0)
-    assert_equal_up_to_flips(buf.permute(0, 3, 1, 2).float().cpu().numpy(), ref2.numpy(), mag2.numpy(), max_frac=0.01, max_ulps=3.2 if bn else 1.0,
+    assert_equal_up_to_flips(buf.permute(0, 3, 1, 2).float().cpu().numpy(), ref2.numpy(), mag2.numpy(), max_frac=0.01, max_ulps=4.2 if bn else 2.0,
                              what="conv1 ragged", slack=slack2.numpy())
 
 
@@ -125,9 +125,11 @@ def test_igemm_conv3x3_policy(dev, B, H, Cin, Cout, stride, res, bn):
     ops.igemm_f16(xb, gin, wk, bias.to(dev), y, gout, B * Ho * Ho, Cout, Cin, 9, relu=True, residual=rb, r_geom=gout if res else None,
                   bn_scale=sb[0].to(dev) if bn else None, bn_shift=sb[1].to(dev) if bn else None, conv_rounding=True)
     out = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
-    # a flip before BatchNorm is scaled by |scale| <= 2.1 on its way out
-    rep = assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.03, max_ulps=3.2 if bn else 1.0, what="conv3x3",
-                                   slack=slack.numpy())
+    # every rounding point of the sequence can flip independently (conv, + bias, BatchNorm, + identity), and a flip before
+    # BatchNorm is scaled by |scale| <= 2.1 on its way out: the cap on the size of a deviation grows with the sequence,
+    # the FRACTION of deviating elements is what separates summation-order noise from different arithmetic
+    cap = (2.0 + (2.2 if bn else 0.0)) + (1.0 if res else 0.0)
+    rep = assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.03, max_ulps=cap, what="conv3x3", slack=slack.numpy())
     REPORT.setdefault("kernel_flip_rates", {})[f"conv3x3 B{B} H{H} {Cin}->{Cout} s{stride}"] = rep
     assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0   # the zero border is left untouched
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
