@@ -1,8 +1,8 @@
 // Fused pose-hypothesis rasteriser for gfx950 (replaces nvdiffrast_render, Utils.py:133-219, plus the
 // A-side of make_crop_data_batch / transform_batch / concat -- see include/fp_amd.h).
 //
-// fp_render_crops = two launches (k_bin, k_raster -- see the pipeline comment below): triangles binned to 16-row strips,
-// strip z-buffer in LDS merged with a 64-bit ds_min on the key
+// fp_render_crops = three launches (k_vertex, k_bin, k_raster -- see the pipeline comment below): per-vertex work once
+// per hypothesis, triangles binned to 16-row strips, strip z-buffer in LDS merged with a 64-bit ds_min on the key
 // (round(z_cam * 2^20) << 32 | tri_id) -- deterministic winner, independent of arrival order -- and a pixel-parallel
 // resolve that writes the network tensor A[n, 0:6] directly (fp16 or fp32), so no intermediate image reaches HBM.
 // Compiled with -ffp-contract=off: the float expression order below is the definition shared with the
@@ -166,26 +166,22 @@ __device__ __forceinline__ void tex_fetch(const float* __restrict__ tex, int Ht,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pipeline of one fp_render_crops call (a counter reset + two launches on the caller's stream, scratch in the caller's workspace):
-//   k_bin    : grid (T/256, N)  one lane per (hypothesis, triangle): projects its three vertices, finds the strips of
-//              FP_STRIP_ROWS rows its clipped bounding box touches
+// Pipeline of one fp_render_crops call (three launches on the caller's stream, scratch in the caller's workspace):
+//   k_vertex : grid (V/256, N)  one lane per (hypothesis, vertex): camera-space position, unsnapped and snapped crop
+//              position, 1/z, Lambert term of the vertex normal  -> VtxRec (8 B, raster) + VtxAttr (24 B, resolve)
+//   k_bin    : grid (T/256, N)  one lane per (hypothesis, triangle): strips of FP_STRIP_ROWS rows it can touch
 //              -> per-(hypothesis, strip) triangle lists (wave-ballot compaction, one atomicAdd per wave and strip)
 //   k_raster : grid (strips, N) one workgroup per (hypothesis, strip): LDS strip z-buffer
-//              phase 1  lanes walk the strip's triangle list: projection + setup, integer edge functions, 64-bit ds_min
-//                       of the depth key
-//              phase 2  lanes = pixels (coalesced): the winner's three vertices are transformed again (position, crop
-//                       position, Lambert term), barycentrics, interpolation, texture, shading, network tensor A
-// Vertex work is RECOMPUTED where it is needed (3 projections per listed triangle, 3 full vertex transforms per covered
-// pixel, ~100 flops each) instead of being written once per (hypothesis, vertex) to HBM and gathered back: the first
-// version's 32 B x N x V record arrays (20 MB per launch at N=252) were written, then re-read by every strip with
-// per-hypothesis addresses (no reuse between hypotheses), and cost a third launch; the mesh itself (140 KB) is shared
-// by every hypothesis and stays in L1 / L2.  Same float expressions as before, so zbuf / tri_id / A are unchanged bit for bit.
+//              phase 1  lanes walk the strip's triangle list: integer edge functions, 64-bit ds_min of the depth key
+//              phase 2  lanes = pixels (coalesced): barycentrics, interpolation, texture, shading, network tensor A
+// Per-vertex work is done once per hypothesis (not once per strip and not three times per pixel), a strip only ever
+// looks at the triangles binned to it, and 16-row strips (20 KiB of LDS) keep 6-7 workgroups resident per CU.
 #define FP_STRIP_ROWS 16
 #define FP_MAX_STRIPS 64          // oh <= 1024
 #define FP_BIG_CELLS 24           // clipped bounding boxes above this many pixels are rasterised cooperatively
 #define FP_BIG_MAX 96             // queue capacity (entries of 56 B)
 
-struct VtxAttr {            // resolve-side vertex record (registers only)
+struct VtxAttr {            // per (hypothesis, vertex), resolve-side
   float xc, yc, zc;        // camera-space position
   float X, Y;              // unsnapped crop-pixel position
   float dk;                // clip(normalize(R n) . (0,0,-1), 0, 1)  (Utils.py:203-206)
@@ -198,12 +194,21 @@ struct BigTri {             // a finished triangle setup parked in LDS (oriented
 };
 
 struct RenderWs {
+  VtxRec* vr;              // [N][V]
+  VtxAttr* va;             // [N][V]
   int* counts;             // [N][strips]
   unsigned short* lists16; // [N][strips][T]   (T <= 65535)
   int* lists32;            // same with 32-bit ids for larger meshes
 };
 
-__device__ __forceinline__ VtxAttr vertex_attr(const fp_mesh& m, const HypConst& h, int v) {
+__global__ __launch_bounds__(256) void k_vertex(fp_mesh m, const float* __restrict__ poses,
+                                                const float* __restrict__ bbox2d, fp_k9 K, int H, int W, int oh, int ow,
+                                                int nstrips, RenderWs ws) {
+  const int n = blockIdx.y;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < nstrips) ws.counts[n * nstrips + threadIdx.x] = 0;
+  if (v >= m.V) return;
+  const HypConst h = load_hyp(poses, bbox2d, K, n, H, W, oh, ow);
   const float vx = m.pos[v * 3], vy = m.pos[v * 3 + 1], vz = m.pos[v * 3 + 2];
   VtxAttr a;
   cam_point(h, vx, vy, vz, a.xc, a.yc, a.zc);
@@ -214,26 +219,18 @@ __device__ __forceinline__ VtxAttr vertex_attr(const fp_mesh& m, const HypConst&
   const float n2 = fmaf(h.P[10], vn[2], fmaf(h.P[9], vn[1], h.P[8] * vn[0]));
   const float len = sqrtf(fmaf(n2, n2, fmaf(n1, n1, n0 * n0)));
   a.dk = clamp01((-n2) / fmaxf(len, 1e-12f));
-  return a;
+  const size_t o = (size_t)n * m.V + v;
+  ws.va[o] = a;
+  ws.vr[o] = project_vertex(h, vx, vy, vz);
 }
 
-__device__ __forceinline__ VtxRec vertex_rec(const fp_mesh& m, const HypConst& h, int v) {
-  return project_vertex(h, m.pos[v * 3], m.pos[v * 3 + 1], m.pos[v * 3 + 2]);
-}
-
-__global__ __launch_bounds__(256) void k_zero_counts(int* __restrict__ counts, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) counts[i] = 0;
-}
-
-__global__ __launch_bounds__(256) void k_bin(fp_mesh m, const float* __restrict__ poses, const float* __restrict__ bbox2d,
-                                             fp_k9 K, int H, int W, int oh, int ow, int nstrips, RenderWs ws) {
+__global__ __launch_bounds__(256) void k_bin(fp_mesh m, int oh, int ow, int nstrips, RenderWs ws) {
   const int n = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   int s0 = 1, s1 = 0;   // empty range
   if (t < m.T) {
-    const HypConst h = load_hyp(poses, bbox2d, K, n, H, W, oh, ow);
-    const VtxRec r0 = vertex_rec(m, h, m.faces[t * 3]), r1 = vertex_rec(m, h, m.faces[t * 3 + 1]), r2 = vertex_rec(m, h, m.faces[t * 3 + 2]);
+    const VtxRec* vr = ws.vr + (size_t)n * m.V;
+    const VtxRec r0 = vr[m.faces[t * 3]], r1 = vr[m.faces[t * 3 + 1]], r2 = vr[m.faces[t * 3 + 2]];
     TriSetup tr;
     if (tri_setup(r0, r1, r2, tr)) {
       const int miny = min(tr.y0, min(tr.y1, tr.y2)), maxy = max(tr.y0, max(tr.y1, tr.y2));
@@ -282,7 +279,8 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
   BigTri* big = reinterpret_cast<BigTri*>(nbig + 4);
   const int tid = threadIdx.x;
   if (tid == 0) *nbig = 0;
-  const HypConst h = load_hyp(poses, bbox2d, K, n, H, W, oh, ow);
+  const VtxRec* vr = ws.vr + (size_t)n * m.V;
+  const VtxAttr* va = ws.va + (size_t)n * m.V;
 
   for (int p = tid; p < npix; p += FP_RASTER_THREADS) zb[p] = FP_KEY_EMPTY;
   __syncthreads();
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
     }
   };
   auto setup = [&](int t, TriSetup& tr, float& iw0, float& iw1, float& iw2, int& i0, int& i1, int& j0, int& j1) -> bool {
-    const VtxRec r0 = vertex_rec(m, h, m.faces[t * 3]), r1 = vertex_rec(m, h, m.faces[t * 3 + 1]), r2 = vertex_rec(m, h, m.faces[t * 3 + 2]);
+    const VtxRec r0 = vr[m.faces[t * 3]], r1 = vr[m.faces[t * 3 + 1]], r2 = vr[m.faces[t * 3 + 2]];
     if (!tri_setup(r0, r1, r2, tr)) return false;
     const int miny = min(tr.y0, min(tr.y1, tr.y2)), maxy = max(tr.y0, max(tr.y1, tr.y2));
     const int minx = min(tr.x0, min(tr.x1, tr.x2)), maxx = max(tr.x0, max(tr.x1, tr.x2));
@@ -379,6 +377,7 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
   __syncthreads();
 
   // ---- phase 2: resolve + shade + write
+  const HypConst h = load_hyp(poses, bbox2d, K, n, H, W, oh, ow);
   const size_t plane = (size_t)oh * ow;
   const float t0 = h.P[3], t1 = h.P[7], t2 = h.P[11];
   const bool normalize = (flags & FP_FLAG_NORMALIZE_XYZ) != 0;
@@ -393,7 +392,7 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
       const int t = (int)(uint32_t)(key & 0xFFFFFFFFull);
       tid_out = t;
       const int fa0 = m.faces[t * 3], fa1 = m.faces[t * 3 + 1], fa2 = m.faces[t * 3 + 2];
-      const VtxAttr A0 = vertex_attr(m, h, fa0), A1 = vertex_attr(m, h, fa1), A2 = vertex_attr(m, h, fa2);
+      const VtxAttr A0 = va[fa0], A1 = va[fa1], A2 = va[fa2];
       // nvdiffrast's per-pixel pass: perspective-correct barycentrics of the winner from its
       // UNSNAPPED vertices in face order, p_k = z_k * (X_k - pixel centre), a0 = p1 x p2, ..., clamped (u, v), 1-u-v
       const float fxp = (float)i + 0.5f, fyp = (float)j + 0.5f;
@@ -488,14 +487,15 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
 // ---------------------------------------------------------------- host side
 static inline size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct WsLayout { size_t counts, lists, total; int nstrips; bool ids16; };
+struct WsLayout { size_t vr, va, counts, lists, total; int nstrips; bool ids16; };
 
 static WsLayout ws_layout(int N, int V, int T, int oh) {
-  (void)V;
   WsLayout L;
   L.nstrips = fp_cdiv(oh, FP_STRIP_ROWS);
   L.ids16 = T <= 65535;
   size_t o = 0;
+  L.vr = o; o = ws_align(o + (size_t)N * V * sizeof(VtxRec));
+  L.va = o; o = ws_align(o + (size_t)N * V * sizeof(VtxAttr));
   L.counts = o; o = ws_align(o + (size_t)N * L.nstrips * sizeof(int));
   L.lists = o; o = ws_align(o + (size_t)N * L.nstrips * T * (L.ids16 ? 2 : 4));
   L.total = o;
@@ -528,17 +528,16 @@ extern "C" int fp_render_crops(const fp_mesh* mesh, const float* poses, const fl
   for (int i = 0; i < 9; ++i) K.v[i] = K9[i];
   unsigned char* w8 = (unsigned char*)workspace;
   RenderWs ws;
-  ws.counts = (int*)(w8 + L.counts);
+  ws.vr = (VtxRec*)(w8 + L.vr); ws.va = (VtxAttr*)(w8 + L.va); ws.counts = (int*)(w8 + L.counts);
   ws.lists16 = L.ids16 ? (unsigned short*)(w8 + L.lists) : nullptr;
   ws.lists32 = L.ids16 ? nullptr : (int*)(w8 + L.lists);
   const float inv_r = 1.0f / (mesh_diameter * 0.5f);
   RenderOut out = {A, color, depth, xyz, normal, zbuf, tri_id};
   hipStream_t st = (hipStream_t)stream;
-  // list counters back to zero (a plain kernel rather than hipMemsetAsync: replaying a captured memset node of this size
-  // aborted inside the runtime on ROCm 7.0)
-  hipLaunchKernelGGL(k_zero_counts, dim3(fp_cdiv(N * L.nstrips, 256)), dim3(256), 0, st, ws.counts, N * L.nstrips);
-  FP_CHECK_LAUNCH("fp_render_crops(zero)");
-  hipLaunchKernelGGL(k_bin, dim3(fp_cdiv(mesh->T, 256), N), dim3(256), 0, st, *mesh, poses, bbox2d, K, H, W, oh, ow, L.nstrips, ws);
+  hipLaunchKernelGGL(k_vertex, dim3(fp_cdiv(mesh->V, 256), N), dim3(256), 0, st, *mesh, poses, bbox2d, K, H, W, oh, ow,
+                     L.nstrips, ws);
+  FP_CHECK_LAUNCH("fp_render_crops(vertex)");
+  hipLaunchKernelGGL(k_bin, dim3(fp_cdiv(mesh->T, 256), N), dim3(256), 0, st, *mesh, oh, ow, L.nstrips, ws);
   FP_CHECK_LAUNCH("fp_render_crops(bin)");
   const size_t lds = (size_t)FP_STRIP_ROWS * ow * sizeof(unsigned long long) + 16 + FP_BIG_MAX * sizeof(BigTri);
   FP_SET_MAX_LDS(k_raster, 160 * 1024);

@@ -82,8 +82,8 @@ int fp_crop_windows(const float* poses /*dev N,16*/, const double* K /*host 9*/,
                     double crop_ratio, int out_w, int out_h, int N, float* tf_to_crops /*dev N,9*/,
                     float* bbox2d /*dev N,4*/, void* stream);
 
-/* bytes of scratch fp_render_crops needs for (N hypotheses, V vertices, T triangles, oh x ow crops): the per-(hypothesis,
- * strip) triangle lists and their counters; caller-owned device memory, no alignment beyond 256 B */
+/* bytes of scratch fp_render_crops needs for (N hypotheses, V vertices, T triangles, oh x ow crops): per-hypothesis
+ * vertex records (32 B/vertex) and per-strip triangle lists; caller-owned device memory, no alignment beyond 256 B */
 size_t fp_workspace_bytes(int N, int V, int T, int oh, int ow);
 
 /* Utils.py:133-219 nvdiffrast_render (dr.rasterize + interpolate x5 + texture + Lambert shading + flips)

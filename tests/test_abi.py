@@ -32,12 +32,12 @@ def test_argument_errors_are_reported_without_gpu():
     assert st == -1 and b"fp_mesh_create" in lib.fp_last_error()
     assert lib.fp_rows_linear_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), 4, 33, 128, 0, None) == -1
     assert b"multiple" in lib.fp_last_error()
-    # scratch = per-strip triangle lists (10 strips of 16 rows, 16-bit ids) + their counters; no per-vertex records
+    # scratch = per-hypothesis vertex records (32 B / vertex) + per-strip triangle lists (10 strips of 16 rows)
     ws = lib.fp_workspace_bytes(252, 2501, 4900, 160, 160)
-    assert 252 * 10 * 4900 * 2 <= ws <= 252 * (10 * 4900 * 2 + 10 * 4) + 4096
+    assert 252 * (2501 * 32 + 10 * 4900 * 2) <= ws <= 252 * (2501 * 32 + 10 * 4900 * 2 + 10 * 4) + 4096
     assert lib.fp_workspace_bytes(0, 2501, 4900, 160, 160) == 0
     big = lib.fp_workspace_bytes(4, 100000, 200000, 160, 160)        # > 65535 triangles: 32-bit ids in the lists
-    assert big >= 4 * 10 * 200000 * 4
+    assert big >= 4 * (100000 * 32 + 10 * 200000 * 4)
     # GEMM geometry / epilogue errors
     from foundationpose_amd.ops import IgemmEpilogue
     G = (C.c_int * 10)(1, 1, 1, 1, 1, 0, 512, 0, 0, 0)
