@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
   const int qd8 = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (qd8 + 1) : r8 * (qd8 + 1) + (xcd - r8) * qd8) + loc;
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
-  const int m0 = p.m_base + bm * BM, n0 = bn * BN;
+  const int m0 = bm * BM, n0 = bn * BN;
   const int Cin = p.Cin, Ktot = 9 * Cin, Wp = p.in.Wp;
   const int ncc = Cin / BK;
   ig_bias_to_lds(p, n0, bias_lds, wid, lane);
@@ -232,10 +232,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
 }
 
 template <int BM, int BN, int TM>
-int sw_launch(const IgemmParams& p, hipStream_t stream, int mtiles) {
+int sw_launch(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDS = ig_lds_main<BM, BN>(2 * sw_prows(BM) * SW_BK * 2 + SW_NSTW * BN * SW_BK * 2) + IG_BIAS_LDS;
   static_assert(LDS <= 160 * 1024, "does not fit the 160 KiB LDS");
-  const long long tiles = (long long)(mtiles >= 0 ? mtiles : fp_cdiv(p.M - p.m_base, BM)) * (p.N / BN);
+  const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
   FP_SET_MAX_LDS((k_conv_sw<BM, BN, TM>), LDS);
   hipLaunchKernelGGL((k_conv_sw<BM, BN, TM>), dim3((unsigned)tiles), dim3(512), LDS, stream, p);
@@ -265,7 +265,7 @@ bool fp_conv3x3_sw_applicable(const IgemmParams& p) {
 
 int fp_conv3x3_sw_tile_rows(const IgemmParams& p) { return sw_tile_rows(p); }
 
-int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream, int mtiles) {
-  if ((p.N % 256) == 0) return sw_launch<256, 256, 4>(p, stream, mtiles);
-  return sw_launch<512, 128, 4>(p, stream, mtiles);
+int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream) {
+  if ((p.N % 256) == 0) return sw_launch<256, 256, 4>(p, stream);
+  return sw_launch<512, 128, 4>(p, stream);
 }

@@ -29,8 +29,8 @@
 #include "igemm_common.h"
 #include "igemm_epilogue.h"
 
-int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream, int mtiles);   // igemm_pp.hip
-int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream, int mtiles);               // conv_sw.hip (shifted-window 3x3)
+int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream);   // igemm_pp.hip
+int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream);               // conv_sw.hip (shifted-window 3x3)
 bool fp_conv3x3_sw_applicable(const IgemmParams& p);
 int fp_conv3x3_sw_tile_rows(const IgemmParams& p);
 
@@ -71,7 +71,7 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   const int q = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
-  const int m0 = p.m_base + bm * BM, n0 = bn * BN;
+  const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
   ig_bias_to_lds(p, n0, bias_lds, wid, lane);
 
@@ -192,13 +192,12 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_
   ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
 }
 
-// mtiles < 0: every row tile from p.m_base to the end; otherwise exactly `mtiles` row tiles
 template <int BM, int BN, int TM, int NST, int BK>
-static int ig_launch(const IgemmParams& p, hipStream_t stream, int mtiles = -1) {
+static int ig_launch(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDS = ig_lds_main<BM, BN>(NST * (BM + BN) * BK * 2) + IG_BIAS_LDS;
   constexpr int THREADS = (BM / (32 * TM)) * (BN / 64) * 64;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  const long long tiles = (long long)(mtiles >= 0 ? mtiles : fp_cdiv(p.M - p.m_base, BM)) * (p.N / BN);
+  const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
   FP_SET_MAX_LDS((k_igemm_f16<BM, BN, TM, NST, BK>), LDS);
   hipLaunchKernelGGL((k_igemm_f16<BM, BN, TM, NST, BK>), dim3((unsigned)tiles), dim3(THREADS), LDS, stream, p);
@@ -225,48 +224,11 @@ static IgemmGeom ig_geom(const fp_igemm_geom* g) {
   return o;
 }
 
-// ---- one layer = one or two launches ------------------------------------------------------------------------------
-// The large-tile kernels hold one workgroup per CU, so a layer of U tiles takes ceil(U / CUs) rounds and the last,
-// partial round leaves most of the chip idle (788 tiles of the 512->512 conv on 256 CUs: 3.08 rounds of work in 4).
-// Whole rounds go to the large-tile kernel; the rows of the partial round go to the 128x128 kernel (two workgroups per
-// CU, a quarter of the work each) launched on a side stream that is forked from and joined back into the caller's stream
-// with events: the two grids are independent (disjoint output rows), so the hardware queues fill the CUs the large
-// tiles leave idle with the small ones.  Fork and join are ordinary event edges: inside a stream capture they become two
-// parallel branches of the graph.  Which rows go where depends only on (M, N, CU count): results are deterministic.
-struct IgSide { hipStream_t s; hipEvent_t fork, join; bool ok; };
-static IgSide* ig_side_stream() {
-  static IgSide side[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  IgSide& d = side[dev & 63];
-  if (!d.s) {
-    // LOWEST priority: the hardware hands a free CU to the large-tile kernel as long as it has workgroups left, so the
-    // small tiles run where and when the last round leaves CUs idle instead of delaying whole rounds
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    d.ok = hipStreamCreateWithPriority(&d.s, hipStreamNonBlocking, least) == hipSuccess &&
-           hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&d.join, hipEventDisableTiming) == hipSuccess;
-  }
-  return d.ok ? &d : nullptr;
-}
-
-static int ig_num_cus() {
-  static int n[64] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (n[dev & 63] == 0) {
-    hipDeviceProp_t prop;
-    n[dev & 63] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-  }
-  return n[dev & 63];
-}
-
 static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
   int sel = 0;
 #ifdef FP_PROFILE_BUILD
-  // profiling builds only (make profile): FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | pp256x256 | pp256x128 | generic |
-  // nosplit forces one schedule; the release library has no environment switches on this path
+  // profiling builds only (make profile): FP_IGEMM_TILE = 128x128 | 256x128 | 256x256 | pp256x256 | pp256x128 | generic
+  // forces one schedule; the release library has no environment switches on this path
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("FP_IGEMM_TILE");
@@ -278,62 +240,24 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
       else if (!strcmp(e, "pp256x256")) forced = 7;
       else if (!strcmp(e, "pp256x128")) forced = 9;
       else if (!strcmp(e, "generic")) forced = 100;   // default selection without the shifted-window kernel
-      else if (!strcmp(e, "nosplit")) forced = 101;   // default selection, one launch per layer
     }
   }
   sel = forced;
 #endif
-  const bool allow_split = sel == 0;
-  const bool sw = (sel == 0 || sel == 101) && fp_conv3x3_sw_applicable(p);
+  const bool sw = sel == 0 && fp_conv3x3_sw_applicable(p);
   if (sel >= 100) sel = 0;
   // measured at the bench shapes (scripts/bench_igemm.py): the 256x256 ping-pong kernel wins where both M and N are
   // large (QKV projection), 128x128 (two workgroups per CU) elsewhere
   if (!sw && sel == 0) sel = ((p.N % 256) == 0 && (p.M >= 150000 || p.N >= 1024)) ? 7 : 1;
   if (sel == 3 && (p.N % 256) != 0) sel = 2;
   if (sel == 7 && (p.N % 256) != 0) sel = 9;
-  // ---- large-tile kernels: whole rounds here, the partial round on the 128x128 kernel
-  int BM = 0, BN = 0;
-  if (sw) { BM = fp_conv3x3_sw_tile_rows(p); BN = BM == 256 ? 256 : 128; }
-  else if (sel == 7) { BM = 256; BN = 256; }
-  else if (sel == 9) { BM = 256; BN = 128; }
-  int main_mtiles = -1;
-  if (BM && allow_split) {
-    const int ncu = ig_num_cus();
-    const long long tiles_m = fp_cdiv(p.M, BM), tiles_n = p.N / BN, U = tiles_m * tiles_n;
-    const long long rounds = U / ncu, rem = U % ncu;
-    if (rounds >= 1 && rem > 0 && rem * 5 <= (long long)ncu * 4) {
-      const long long mt = (rounds * ncu) / tiles_n;
-      if (mt >= 1 && mt < tiles_m) main_mtiles = (int)mt;
-    }
-  }
-  IgSide* side = main_mtiles >= 0 ? ig_side_stream() : nullptr;
-  if (main_mtiles >= 0 && side) {
-    if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess) {
-      fp_set_error("fp_igemm_f16_fwd: cannot fork the side stream");
-      return FP_ERR_LAUNCH;
-    }
-  } else {
-    main_mtiles = -1;
-  }
-  int err;
-  if (sw) err = fp_conv3x3_sw_launch(p, stream, main_mtiles);
-  else if (sel >= 7) err = fp_igemm_pp_launch(p, sel - 7, stream, main_mtiles);
+  if (sw) return fp_conv3x3_sw_launch(p, stream);
+  if (sel >= 7) return fp_igemm_pp_launch(p, sel - 7, stream);
 #ifdef FP_PROFILE_BUILD
-  else if (sel == 2) err = ig_launch<256, 128, 2, 3, 64>(p, stream);
-  else if (sel == 3) err = ig_launch<256, 256, 4, 2, 64>(p, stream);
+  if (sel == 2) return ig_launch<256, 128, 2, 3, 64>(p, stream);
+  if (sel == 3) return ig_launch<256, 256, 4, 2, 64>(p, stream);
 #endif
-  else err = ig_launch<128, 128, 2, 2, 64>(p, stream);
-  if (err) return err;
-  if (main_mtiles >= 0) {
-    IgemmParams r = p;
-    r.m_base = main_mtiles * BM;
-    if (int e = ig_launch<128, 128, 2, 2, 64>(r, side->s)) return e;
-    if (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
-      fp_set_error("fp_igemm_f16_fwd: cannot join the side stream");
-      return FP_ERR_LAUNCH;
-    }
-  }
-  return FP_OK;
+  return ig_launch<128, 128, 2, 2, 64>(p, stream);
 }
 
 
@@ -364,6 +288,5 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = (e.flags & FP_IGEMM_RELU) ? 1 : 0;
   p.round_acc = (e.flags & FP_IGEMM_ROUND_ACC) ? 1 : 0;
   p.in = ig_geom(x_geom); p.out = ig_geom(y_geom); p.res = e.residual ? ig_geom(e.r_geom) : ig_geom(y_geom);
-  p.m_base = 0;
   return ig_dispatch(p, (hipStream_t)stream);
 }

@@ -49,8 +49,6 @@ struct IgemmParams {
   _Float16* Ype;        // last conv): Ype[m][n] = f16(f32(y[m][n]) + pe[m % pe_period][n]), a plain (M, N) matrix
   int pe_period;
   int M, N, Cin, taps;
-  int m_base;           // first GEMM row of this launch (a layer may be split into a main launch of whole rounds of large
-                        // tiles and a launch of small tiles over the remaining rows, see ig_dispatch in igemm.hip)
   int relu;
   int round_acc;        // FP_IGEMM_ROUND_ACC: the accumulator is rounded to fp16 BEFORE the bias is added (nn.Conv2d under
                         // autocast: ATen adds the bias to the fp16 convolution output); 0: one rounding of acc + bias (nn.Linear)

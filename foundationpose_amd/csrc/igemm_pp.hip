@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
   const int q = nwg >> 3, r8 = nwg & 7;
   const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
-  const int m0 = p.m_base + bm * BM, n0 = bn * BN;
+  const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
   ig_bias_to_lds(p, n0, bias_lds, wid, lane);
 
@@ -200,10 +200,10 @@ __global__ __launch_bounds__(512, 1) void k_igemm_pp(IgemmParams p) {
 }
 
 template <int BM, int BN, int TM, int DBG>
-static int ig_pp_launch(const IgemmParams& p, hipStream_t stream, int mtiles) {
+static int ig_pp_launch(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDS = ig_lds_main<BM, BN>(4 * (BM + BN) * 32 * 2) + IG_BIAS_LDS;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  const long long tiles = (long long)(mtiles >= 0 ? mtiles : fp_cdiv(p.M - p.m_base, BM)) * (p.N / BN);
+  const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
   FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
   FP_SET_MAX_LDS((k_igemm_pp<BM, BN, TM, DBG>), LDS);
   hipLaunchKernelGGL((k_igemm_pp<BM, BN, TM, DBG>), dim3((unsigned)tiles), dim3(512), LDS, stream, p);
@@ -214,19 +214,19 @@ static int ig_pp_launch(const IgemmParams& p, hipStream_t stream, int mtiles) {
 
 // variant: 0 = 256x256 (N % 256 == 0), otherwise 256x128.  The resource-isolation builds (DBG != 0: results wrong by
 // construction) exist only in a profiling build (make PROFILE=1), selected there by FP_IGEMM_DBG.
-int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream, int mtiles) {
+int fp_igemm_pp_launch(const IgemmParams& p, int variant, hipStream_t stream) {
 #ifdef FP_PROFILE_BUILD
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("FP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
   if (variant == 0 && dbg) {
     switch (dbg) {
-      case 1: return ig_pp_launch<256, 256, 4, 1>(p, stream, mtiles);
-      case 2: return ig_pp_launch<256, 256, 4, 2>(p, stream, mtiles);
-      case 3: return ig_pp_launch<256, 256, 4, 3>(p, stream, mtiles);
-      default: return ig_pp_launch<256, 256, 4, 9>(p, stream, mtiles);
+      case 1: return ig_pp_launch<256, 256, 4, 1>(p, stream);
+      case 2: return ig_pp_launch<256, 256, 4, 2>(p, stream);
+      case 3: return ig_pp_launch<256, 256, 4, 3>(p, stream);
+      default: return ig_pp_launch<256, 256, 4, 9>(p, stream);
     }
   }
 #endif
-  if (variant == 0) return ig_pp_launch<256, 256, 4, 0>(p, stream, mtiles);
-  return ig_pp_launch<256, 128, 2, 0>(p, stream, mtiles);
+  if (variant == 0) return ig_pp_launch<256, 256, 4, 0>(p, stream);
+  return ig_pp_launch<256, 128, 2, 0>(p, stream);
 }

@@ -152,8 +152,9 @@ def _conv_params(sd, conv_p, bn_p):
 class _HipEncoder:
     """The encoder on libfp_amd.so only: patch-embed conv (fp_conv7x7s2_bn_relu_fwd) + 15 implicit-GEMM 3x3 convs
     (fp_igemm_f16_fwd) with the conv / BatchNorm / residual / ReLU rounding sequence of autocast in their epilogues.
-    Activations are NHWC fp16 with a 1-pixel zero border; one buffer set per (batch, H, W) is allocated on first use and
-    kept (a captured hipGraph holds raw pointers into it, so sets are never dropped or reallocated); the A|B channel
+    Activations are NHWC fp16 with a 1-pixel zero border; one buffer set per (batch, H, W, slot) is allocated on first use
+    and kept (a captured hipGraph holds raw pointers into it, so sets are never dropped or reallocated; `slot` separates
+    callers that run concurrently on different streams); the A|B channel
     concat is a strided store of the stem's last conv (refine_network.py:82-85), and the last conv writes the
     (N, 400, 512) token matrix directly."""
 
@@ -173,8 +174,8 @@ class _HipEncoder:
         self.device = device
         self._bufs = {}
 
-    def _buffers(self, n, H, W):
-        key = (n, H, W)
+    def _buffers(self, n, H, W, slot):
+        key = (n, H, W, slot)
         b = self._bufs.get(key)
         if b is None:
             z = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=self.device)
@@ -196,12 +197,12 @@ class _HipEncoder:
         return ops.igemm_f16(x, gin, c["w"], c["bias"], y, gout, Bn * Ho * Wo, Cout, Cin, 9, relu=relu, residual=res, r_geom=gres,
                              bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True, pe=pe, y_pe=y_pe)
 
-    def __call__(self, AB):
+    def __call__(self, AB, slot=0):
         """AB (2n,6,H,W) fp16 -> (tokens (n, H/8 * W/8, 512) fp16 before the positional table,
         x16 = f16(f32(tokens) + pe): the in_proj operand, written by the same epilogue)"""
         n2, _, H, W = AB.shape
         n = n2 // 2
-        b = self._buffers(n, H, W)
+        b = self._buffers(n, H, W, slot)
         h1, w1, h2, w2, h3, w3 = b["dims"]
         G = ops.IgemmGeom.image
         ops.conv7x7s2_bn_relu(AB, self.c1_w, self.c1_b, self.c1_scale, self.c1_shift, b["P1"], 1)
@@ -252,8 +253,8 @@ class _HipRowsLinear:
         self.w = w.to(torch.float16).contiguous()
         self.b = _r16(b.float())
 
-    def __call__(self, x, round_f16=True, out_f16=False):
-        return ops.rows_linear(x, self.w, self.b, round_f16=round_f16, out_f16=out_f16)
+    def __call__(self, x, round_f16=True, out_f16=False, out=None):
+        return ops.rows_linear(x, self.w, self.b, round_f16=round_f16, out_f16=out_f16, out=out)
 
 
 class _HipMHA:
@@ -314,11 +315,12 @@ class RefinePlan:
                                     sd[f"{name}_head.1.weight"].to(self.dtype), sd[f"{name}_head.1.bias"].to(self.dtype))
 
     @torch.inference_mode()
-    def __call__(self, AB):
-        """AB (2N,6,H,W) in the plan's dtype -> {'trans': (N,3) f32, 'rot': (N,3|6) f32}"""
+    def __call__(self, AB, slot=0):
+        """AB (2N,6,H,W) in the plan's dtype -> {'trans': (N,3) f32, 'rot': (N,3|6) f32}.  slot: activation-buffer set
+        (callers that overlap on different streams use different slots)"""
         out = {}
         if self.hip:
-            tok16, x16 = self.enc(AB)
+            tok16, x16 = self.enc(AB, slot)
             for name, (layer, head) in self.heads.items():
                 # Linear and the token mean commute: mean_t(x_t W^T + b) = (mean_t x_t) W^T + b, so the 512 -> 3|6 head
                 # runs on N rows instead of N*400 (refine_network.py:90-91); the result is held in fp16 by the reference
@@ -347,13 +349,18 @@ class ScorePlan:
             self.lin_w, self.lin_b = sd["linear.weight"].to(self.dtype), sd["linear.bias"].to(self.dtype)
 
     @torch.inference_mode()
-    def features(self, AB):
-        """(2n,6,H,W) -> pooled per-hypothesis features (n,512), fp16 on the HIP plan (score_network.py:60-74)"""
+    def features(self, AB, slot=0, out=None):
+        """(2n,6,H,W) -> pooled per-hypothesis features (n,512), fp16 on the HIP plan (score_network.py:60-74); written
+        into `out` if given (HIP plan)"""
         if self.hip:
-            _, x16 = self.enc(AB)
+            _, x16 = self.enc(AB, slot)
             # out_proj and the token mean commute (score_network.py:73-74): pool the attention output, project N rows
-            return self.att.out_rows(ops.colmean_f16(self.att.context(x16)), out_f16=True)
-        return self.att(self.enc(AB)).float().mean(dim=1)
+            return self.att.out_rows(ops.colmean_f16(self.att.context(x16)), out_f16=True, out=out)
+        f = self.att(self.enc(AB)).float().mean(dim=1)
+        if out is not None:
+            out.copy_(f)
+            return out
+        return f
 
     @torch.inference_mode()
     def head(self, feats, L):

@@ -33,8 +33,9 @@ class GraphedTracker:
         # everything the captured kernels address by raw pointer and that is not allocated inside the capture belongs to
         # the tracker: the rasteriser scratch here, the encoder's activation buffers by key in the plan (never dropped)
         oh, ow = int(refiner.cfg["input_resize"][0]), int(refiner.cfg["input_resize"][1])
-        self.workspace = torch.empty(max(16, ops.workspace_bytes(self.N, self.handle.V, self.handle.T, oh, ow)),
-                                     dtype=torch.uint8, device=self.dev)
+        # (one scratch per concurrently running sub-batch of the refiner, overlap.py)
+        self.workspace = [torch.empty(max(16, ops.workspace_bytes(b - a, self.handle.V, self.handle.T, oh, ow)),
+                                      dtype=torch.uint8, device=self.dev) for a, b in refiner.sub.parts(self.N)]
         self.poses_out = None
         self.graph = None
 

@@ -133,9 +133,10 @@ def workspace_bytes(N, V, T, oh=160, ow=160):
 
 
 def _workspace(nbytes, device):
+    """library-side default scratch: one per (device, stream) -- launches on different streams may overlap"""
     if nbytes == 0:
         return None
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -354,15 +355,18 @@ def colmean_f16(x, gamma=None, beta=None, eps=1e-5, resid32=None):
 ROWS_ROUND_F16, ROWS_X_F16, ROWS_Y_F16 = 1, 2, 4
 
 
-def rows_linear(x, w, bias=None, round_f16=False, out_f16=False):
+def rows_linear(x, w, bias=None, round_f16=False, out_f16=False, out=None):
     """y = x @ w.T + bias for a few hundred rows: x (M,K) f32|f16, w (N,K) f16, bias (N) f32 -> (M,N) f32 (rounded to
-    fp16 values if round_f16) or fp16 (out_f16) (fp_rows_linear_fwd)"""
+    fp16 values if round_f16) or fp16 (out_f16) (fp_rows_linear_fwd).  out: optional (M,N) destination of that dtype"""
     if not (torch.is_tensor(x) and x.dtype in (torch.float32, torch.float16)):
         raise _lib.FpAmdError("rows_linear: x must be an f32 or f16 tensor")
     x = _dev(x, x.dtype, "x"); w = _dev(w, torch.float16, "w"); b = _dev(bias, torch.float32, "bias")
     M, K = (int(v) for v in x.shape)
     N = int(w.shape[0])
-    y = torch.empty((M, N), dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
+    ydt = torch.float16 if out_f16 else torch.float32
+    y = torch.empty((M, N), dtype=ydt, device=x.device) if out is None else _dev(out, ydt, "out")
+    if tuple(y.shape) != (M, N):
+        raise _lib.FpAmdError(f"rows_linear: out has shape {tuple(y.shape)}, expected {(M, N)}")
     flags = (ROWS_ROUND_F16 if round_f16 else 0) | (ROWS_X_F16 if x.dtype == torch.float16 else 0) | (ROWS_Y_F16 if out_f16 else 0)
     _lib.check(_lib.lib().fp_rows_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, K, N, flags, _stream(x)), "fp_rows_linear_fwd")
     return y

@@ -14,6 +14,7 @@ from . import ops
 from .Utils import get_mesh_handle, make_mesh_tensors
 from .engine import RefinePlan
 from .h5_dataset import PoseRefinePairH5Dataset
+from .overlap import SubBatches
 from .pose_dataset import BatchPoseData
 from .refine_network import RefineNet
 
@@ -83,9 +84,12 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
 class PoseRefinePredictor:
     run_name = "2023-10-28-18-33-37"
 
-    def __init__(self, cfg=None, state_dict=None, weights_root=None, device="cuda", precision="fp16", channels_last=True):
+    def __init__(self, cfg=None, state_dict=None, weights_root=None, device="cuda", precision="fp16", channels_last=True,
+                 n_streams=2):
         """precision='fp16': the reference's deployed autocast configuration on libfp_amd.so (engine.py);
-        'fp32': fp32 torch ops, no autocast (`amp=False` in the reference)"""
+        'fp32': fp32 torch ops, no autocast (`amp=False` in the reference).  n_streams: hypothesis sub-batches that run
+        concurrently (overlap.py); 1 = one launch sequence over the whole batch"""
+        self.sub = SubBatches(n_streams)
         self.amp = precision != "fp32"
         if cfg is None or state_dict is None:
             cfg, state_dict, ckpt_dir = load_run(self.run_name, weights_root)
@@ -124,43 +128,71 @@ class PoseRefinePredictor:
             self._plan_dev = dev
         return self._plan
 
-    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, AB=None, workspace=None):
+    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, workspace=None):
         """The refine loop on device tensors only (predict_pose_refine.py:182-235): per iteration fp_crop_windows ->
         fp_render_crops (A) + fp_warp_crops (B) -> RefineNet plan -> fp_pose_update.  No host round trip, no host-side
         tensor creation: the whole call is capturable in a hipGraph (foundationpose_amd/graphs.py), which then passes
-        its own rasteriser `workspace`.
+        its own rasteriser scratch: `workspace` = one uint8 tensor per part of `self.sub.parts(N)` (or a single tensor
+        when there is one part).  Hypotheses are independent through all iterations, so the parts run the whole loop on
+        concurrent streams (overlap.py) and are joined once at the end.
         -> (poses (N,4,4), trans_delta (N,3) in metres, rot_mat_delta (N,3,3)) of the last iteration, as the reference
         keeps them in last_trans_update / last_rot_update (predict_pose_refine.py:238-239)"""
         plan = self.plan()
         N = poses.shape[0]
+        dev = poses.device
         oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
         tn = self.cfg["trans_normalizer"]
         tn = [float(tn)] * 3 if isinstance(tn, (int, float)) else [float(v) for v in tn]
         normalize = bool(self.cfg["normalize_xyz"])
-        if AB is None:
-            AB = torch.empty((2 * N, 6, oh, ow), dtype=plan.dtype, device=poses.device)
-        trans_delta = torch.empty((N, 3), dtype=torch.float32, device=poses.device)
-        rot_delta = torch.empty((N, 3, 3), dtype=torch.float32, device=poses.device)
-        out = None
+        parts = self.sub.parts(N)
+        if workspace is not None and torch.is_tensor(workspace):
+            if len(parts) != 1:
+                raise ValueError(f"refine_device: {len(parts)} parts need a list of {len(parts)} workspaces")
+            workspace = [workspace]
+        poses_out = torch.empty((N, 4, 4), dtype=torch.float32, device=dev)
+        trans_delta = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        rot_delta = torch.empty((N, 3, 3), dtype=torch.float32, device=dev)
+        if iteration <= 0:
+            poses_out.copy_(poses)
+        streams = self.sub.streams(dev, len(parts))
+        self.sub.fork(streams)
+        P = [poses[a:b] for a, b in parts]
+        AB = [None] * len(parts)
+        raw = [None] * len(parts)
         for it in range(iteration):
-            tf_to_crops, bbox2d = ops.crop_windows(poses, K, mesh_diameter, self.cfg["crop_ratio"], (ow, oh))
-            if N == 2:
-                # reference broadcasting quirk (SURVEY App. D.5): with exactly two poses transform_pts pairs pose i with
-                # corner i, so both hypotheses are rendered with [umin_0, vmin_0, umax_1, vmax_1]
-                bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
-            ops.render_crops(mesh_handle, poses, bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
-                             xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[:N], workspace=workspace)
-            ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops, K, poses, mesh_diameter, ops.MODE_REFINE,
-                           normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[N:])
-            out = plan(AB)
             last = it + 1 == iteration
-            poses = ops.pose_update(out["trans"], out["rot"], poses, rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
-                                    trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
-                                    mesh_diameter=float(mesh_diameter), trans_delta_out=trans_delta if last else None,
-                                    rot_delta_out=rot_delta if last else None, trans_rep=str(self.cfg["trans_rep"]), K=K,
-                                    tf_to_crops=tf_to_crops, input_w=float(self.cfg["input_resize"][0]))
-        self.last_raw_output = out     # raw network outputs of the last iteration (debugging / tests)
-        return poses, trans_delta, rot_delta
+            for h, (a, b) in enumerate(parts):
+                n = b - a
+                with torch.cuda.stream(streams[h]):
+                    if AB[h] is None:
+                        AB[h] = torch.empty((2 * n, 6, oh, ow), dtype=plan.dtype, device=dev)
+                    tf_to_crops, bbox2d = ops.crop_windows(P[h], K, mesh_diameter, self.cfg["crop_ratio"], (ow, oh))
+                    if N == 2:
+                        # reference broadcasting quirk (SURVEY App. D.5): with exactly two poses transform_pts pairs pose i
+                        # with corner i, so both hypotheses are rendered with [umin_0, vmin_0, umax_1, vmax_1]
+                        bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
+                    ops.render_crops(mesh_handle, P[h], bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
+                                     xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[h][:n],
+                                     workspace=None if workspace is None else workspace[h])
+                    ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops, K, P[h], mesh_diameter, ops.MODE_REFINE,
+                                   normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[h][n:])
+                    raw[h] = plan(AB[h], slot=h)
+                    P[h] = ops.pose_update(raw[h]["trans"], raw[h]["rot"], P[h], rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
+                                           trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
+                                           mesh_diameter=float(mesh_diameter), out=poses_out[a:b] if last else None,
+                                           trans_delta_out=trans_delta[a:b] if last else None,
+                                           rot_delta_out=rot_delta[a:b] if last else None, trans_rep=str(self.cfg["trans_rep"]), K=K,
+                                           tf_to_crops=tf_to_crops, input_w=float(self.cfg["input_resize"][0]))
+        self.sub.join(streams)
+        self._raw_parts = raw          # raw network outputs of the last iteration (debugging / tests): last_raw_output
+        return poses_out, trans_delta, rot_delta
+
+    @property
+    def last_raw_output(self):
+        raw = getattr(self, "_raw_parts", None)
+        if not raw or raw[0] is None:
+            return None
+        return {k: torch.cat([r[k] for r in raw], 0) for k in raw[0]}
 
     @torch.inference_mode()
     def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None,

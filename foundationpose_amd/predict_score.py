@@ -8,6 +8,7 @@ from .Utils import get_mesh_handle, make_mesh_tensors
 from .engine import ScorePlan
 from .h5_dataset import ScoreMultiPairH5Dataset
 from .pose_dataset import BatchPoseData
+from .overlap import SubBatches
 from .predict_pose_refine import _Cfg, load_run
 from .score_network import ScoreNetMultiPair
 
@@ -48,7 +49,8 @@ class ScorePredictor:
     run_name = "2024-01-11-20-02-45"
 
     def __init__(self, amp=True, cfg=None, state_dict=None, weights_root=None, device="cuda", precision=None,
-                 channels_last=True):
+                 channels_last=True, n_streams=2):
+        self.sub = SubBatches(n_streams)      # hypothesis sub-batches that run concurrently (overlap.py); 1 = none
         if precision is None:
             precision = "fp16" if amp else "fp32"
         self.amp = precision != "fp32"
@@ -94,11 +96,22 @@ class ScorePredictor:
         rgb_t = torch.as_tensor(rgb, device=dev).to(torch.float).contiguous()
         depth_t = torch.as_tensor(depth, device=dev, dtype=torch.float).contiguous()
         oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
-        AB = torch.empty((2 * N, 6, oh, ow), dtype=plan.dtype, device=dev)
-        batch = make_crop_data_batch(self.cfg["input_resize"], poses, mesh, rgb_t, depth_t, K,
-                                     crop_ratio=self.cfg["crop_ratio"], glctx=glctx, mesh_tensors=mesh_tensors,
-                                     dataset=self.dataset, cfg=self.cfg, mesh_diameter=mesh_diameter, AB=AB)
-        feats = plan.features(batch.AB)
+        # the encoder + per-hypothesis attention see one hypothesis at a time: sub-batches on concurrent streams
+        # (overlap.py), joined before the cross-hypothesis attention, which needs all N feature rows
+        parts = self.sub.parts(N)
+        feats = torch.empty((N, 512), dtype=plan.dtype, device=dev)
+        streams = self.sub.streams(dev, len(parts))
+        self.sub.fork(streams)
+        batches = []
+        for h, (a, b) in enumerate(parts):
+            with torch.cuda.stream(streams[h]):
+                AB = torch.empty((2 * (b - a), 6, oh, ow), dtype=plan.dtype, device=dev)
+                batch = make_crop_data_batch(self.cfg["input_resize"], poses[a:b], mesh, rgb_t, depth_t, K,
+                                             crop_ratio=self.cfg["crop_ratio"], glctx=glctx, mesh_tensors=mesh_tensors,
+                                             dataset=self.dataset, cfg=self.cfg, mesh_diameter=mesh_diameter, AB=AB)
+                plan.features(batch.AB, slot=h, out=feats[a:b])
+                batches.append(batch)
+        self.sub.join(streams)
         if feature_exchange is not None:
             feats = feature_exchange(feats)
         # bs == N in the reference (predict_score.py:186), so its pairwise tournament always ends after one round
@@ -108,5 +121,7 @@ class ScorePredictor:
             # debug canvas (predict_score.py:27-52, :219-223): the crops of all hypotheses, best score first
             from .vis import crop_rows_canvas
             ids = scores.argsort(descending=True).cpu().numpy()
-            return scores, crop_rows_canvas(batch.AB[:N].float().cpu().numpy(), batch.AB[N:].float().cpu().numpy(), ids=ids)
+            A = np.concatenate([bt.AB[: bt.AB.shape[0] // 2].float().cpu().numpy() for bt in batches], 0)
+            B = np.concatenate([bt.AB[bt.AB.shape[0] // 2:].float().cpu().numpy() for bt in batches], 0)
+            return scores, crop_rows_canvas(A, B, ids=ids)
         return scores, None

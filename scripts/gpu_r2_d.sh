@@ -2,6 +2,8 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 T=r02d
+echo "== sanity (plain torch on the GPU)"; timeout 200 python -c "import torch; x=torch.ones(1<<20,device='cuda'); y=(x*2).sum().item(); print('torch ok', y)" 2>&1 | tail -2
+if ! timeout 100 python -c "import torch; assert torch.ones(8,device='cuda').sum().item()==8" >/dev/null 2>&1; then echo "BOX BROKEN: plain torch fails"; exit 7; fi
 echo "== kernels"; timeout 600 python -m pytest tests/test_gpu_amp.py -q -k "not 252" > gpurun_out/${T}_kernels.log 2>&1; tail -6 gpurun_out/${T}_kernels.log
 echo "== graph / raster tests"; timeout 400 python -m pytest tests/test_gpu_parity.py -q -k "render or raster or warp or golden or pose_update or graph or tracker" > gpurun_out/${T}_raster.log 2>&1; tail -4 gpurun_out/${T}_raster.log | cut -c1-300
 echo "== per-layer igemm (split, low-priority side stream)"; timeout 200 python scripts/bench_igemm.py > gpurun_out/${T}_igemm.log 2>&1; grep -E "stem|joint|linear" gpurun_out/${T}_igemm.log | grep -v "false"

@@ -406,6 +406,37 @@ def test_graphed_tracker_replays_the_eager_result(scene, dev, gmesh, frame):
     assert torch.equal(b, c)
 
 
+def test_sub_batches_on_concurrent_streams_change_nothing(scene, dev, gmesh, frame):
+    """overlap.py: the refiner's / scorer's hypothesis sub-batches on two streams give the bits of one batch on one stream
+    (same kernels and summation order per hypothesis), eagerly and inside a captured graph"""
+    from foundationpose_amd.graphs import GraphedTracker
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    P = scene["poses"][:75]                      # odd count: parts of 38 + 37
+    rgb, depth, xyz = frame["rgb_t"], frame["depth_t"], frame["xyz_t"]
+    res = {}
+    for ns in (1, 2, 3):
+        refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev, n_streams=ns)
+        scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), device=dev, n_streams=ns)
+        assert len(refiner.sub.parts(len(P))) == min(ns, 2) and len(refiner.sub.parts(63)) == 1
+        p, _ = refiner.predict(rgb, depth, scene["K"], P, xyz, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=3)
+        s, _ = scorer.predict(rgb, depth, scene["K"], p, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+        res[ns] = (p.clone(), s.clone(), refiner.last_trans_update.clone(), refiner.last_rot_update.clone(),
+                   {k: v.clone() for k, v in refiner.last_raw_output.items()})
+        if ns == 2:
+            trk = GraphedTracker(refiner, gmesh, scene["diameter"], scene["K"], 480, 640, n_hyp=len(P), iteration=3, device=dev).capture()
+            assert len(trk.workspace) == 2
+            g = trk.step(scene["rgb"].astype(np.float32), scene["depth"], P).clone()
+            e = trk.step_eager(scene["rgb"].astype(np.float32), scene["depth"], P).clone()
+            assert torch.equal(g, e)
+    for ns in (2, 3):
+        for a, b in zip(res[1][:4], res[ns][:4]):
+            assert torch.equal(a, b), ns
+        for k in res[1][4]:
+            assert torch.equal(res[1][4][k], res[ns][4][k])
+
+
 def test_estimator_track_graph_matches_eager(scene, dev):
     from foundationpose_amd.estimater import FoundationPose
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
