@@ -1,16 +1,16 @@
 // Patch-embed convolution of both encoders (refine_network.py:38, score_network.py:37: ConvBNReLU(6 -> 64, 7x7,
 // stride 2, pad 3)) for gfx950, NHWC output.  HBM-bound by construction (0.48 GFLOP against 1.95 MB per pair of
 // images), so the kernel is organised around streaming:
-//   * persistent workgroups (one per CU, 8 waves): wave w owns output channels 32*(w&1)..+32 and every fourth pixel tile;
-//     its 32 x 294 weights are loaded ONCE, straight from the PyTorch (64, 6*7*7) layout, into MFMA A-fragments that
-//     live in registers for the whole launch (84 VGPRs, so two waves fit per SIMD and overlap each other's LDS reads,
-//     epilogue and MFMAs; the first version kept all 64 channels in one wave: 337 registers, one wave per SIMD)
+//   * persistent workgroups of four waves, two per CU (61 KB of LDS each): while one waits for its input patch the other
+//     multiplies.  A wave owns a tile of 32 output pixels and ALL 64 output channels: the 64 x 294 weights are loaded
+//     ONCE, straight from the PyTorch (64, 6*7*7) layout, into MFMA A-fragments that live in registers for the whole
+//     launch (168 VGPRs), so every B-fragment read from LDS feeds two MFMAs (the first versions split the channels
+//     over two waves and read every fragment twice: LDS reads, not MFMA or HBM, set their pace)
 //     (k re-ordered as (c, ky, kx[8]) = 42 groups of 8 -> 21 k-steps of v_mfma_f32_32x32x16_f16; kx = 7 is a zero weight);
 //   * work unit = (image, band of 8 output rows): its 6 x 21 x (W+16) input patch goes HBM -> LDS by
-//     global_load_lds_dwordx4 (zero padding comes from a 16-byte zero block, so the DMA stays lane-linear), double
-//     buffered: the patch of band t+1 is in flight while band t is multiplied;
+//     global_load_lds_dwordx4 (zero padding comes from a 16-byte zero block, so the DMA stays lane-linear);
 //   * B-fragment of a lane = 8 consecutive input pixels of one (c, ky) row starting at 2*ox - 3: five conflict-free
-//     ds_read_b32 + four v_alignbit (the run starts on an odd element), no im2col, no index table;
+//     dword reads + four v_alignbit (the run starts on an odd element), requested one k-step ahead; no im2col, no index table;
 //   * D[channel][pixel] accumulators go through the reference's autocast op sequence -- conv output rounded to fp16,
 //     + bias (fp16), eval BatchNorm (fp32 statistics) rounded to fp16, ReLU -- are transposed through a wave-private
 //     swizzled LDS tile and leave as 16-byte stores: 128 contiguous bytes per pixel (all 64 channels).
@@ -26,8 +26,11 @@ typedef unsigned int uint4_ __attribute__((ext_vector_type(4)));
 #define C1_ROWS 8                    // output rows per band
 #define C1_PR (2 * C1_ROWS + 5)      // input rows per band
 #define C1_KS 21                     // k-steps of 16 = 42 (c, ky) groups of 8 kx
-#define C1_THREADS 512
+#define C1_WAVES 4
+#define C1_THREADS (64 * C1_WAVES)
 #define C1_MAXW 256
+#define C1_VEC_BYTES (3 * 64 * 4)    // bias | BatchNorm scale | shift as fp32, in LDS
+#define C1_ETILE 4096                // wave-private 32 px x 64 ch transpose tile
 
 __device__ __attribute__((aligned(16))) const unsigned int c1_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -51,7 +54,7 @@ __device__ __forceinline__ void c1_stage(const Conv1Params& p, int band, unsigne
   const int nchunks = C1_CIN * C1_PR * cpr;
   const _Float16* Xb = p.X + (size_t)b * C1_CIN * p.Hin * p.Win;
   const int lane = tid & 63, wid = tid >> 6;
-  // wave-instruction k of this wave covers chunks [64*(4*k + wid), +64): LDS destination is lane-linear
+  // wave-instruction k of this wave covers chunks [64*(C1_WAVES*k + wid), +64): LDS destination is lane-linear
   for (int base = wid * 64; base < nchunks; base += C1_THREADS) {
     const int ch = base + lane;
     const void* src = c1_zero16;
@@ -66,124 +69,137 @@ __device__ __forceinline__ void c1_stage(const Conv1Params& p, int band, unsigne
   }
 }
 
+// two workgroups of four waves per CU (one wave of each per SIMD): while one waits for its patch the other multiplies
 __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int px = lane & 31, kh = lane >> 5;
-  const int hsel = wid & 1;            // channel half of this wave
-  const int tslot = wid >> 1;          // pixel-tile slot 0..3
   const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;  // DMA may overrun by < 64 chunks
-  unsigned char* patch0 = smem;
-  unsigned char* patch1 = smem + patch_bytes;
-  unsigned char* etile = smem + 2 * patch_bytes + wid * 2048;   // wave-private 32 px x 32 ch transpose tile
+  unsigned char* patch = smem;
+  float* vec = reinterpret_cast<float*>(smem + patch_bytes);          // [bias | scale | shift][64]
+  unsigned char* etile = smem + patch_bytes + C1_VEC_BYTES + wid * C1_ETILE;
 
-  // ---- weights -> register-resident A fragments: wf[ks] = W[hsel*32 + px][group 2*ks + kh][0..7]
-  half8 wf[C1_KS];
-#pragma unroll
-  for (int ks = 0; ks < C1_KS; ++ks) {
-    const int g = 2 * ks + kh;          // (c, ky) group
-    const _Float16* w = p.W + (size_t)(hsel * 32 + px) * 294 + g * 7;   // c*49 + ky*7 == g*7
-#pragma unroll
-    for (int e = 0; e < 7; ++e) wf[ks][e] = w[e];
-    wf[ks][7] = (_Float16)0.f;
+  if (tid < 64) {
+    vec[tid] = p.bias ? p.bias[tid] : 0.f;
+    vec[64 + tid] = p.scale ? p.scale[tid] : 1.f;
+    vec[128 + tid] = p.scale ? p.shift[tid] : 0.f;
   }
-  // bias / BN scale / shift of this lane's 16 output channels: channel = hsel*32 + 8*g4 + 4*kh + e
-  typedef _Float16 half2b_ __attribute__((ext_vector_type(2)));
-  half2b_ bi2[4][2];
-  float sc[4][4], sh[4][4];
   const bool has_bn = p.scale != nullptr;
+
+  // ---- weights -> register-resident A fragments, both channel halves: wf[h][ks] = W[32 h + px][group 2*ks + kh][0..7]
+  half8 wf[2][C1_KS];
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int chn = hsel * 32 + 8 * g4 + 4 * kh + e;
-      bi2[g4][e >> 1][e & 1] = (_Float16)(p.bias ? p.bias[chn] : 0.f);
-      sc[g4][e] = has_bn ? p.scale[chn] : 1.f;
-      sh[g4][e] = has_bn ? p.shift[chn] : 0.f;
+    for (int ks = 0; ks < C1_KS; ++ks) {
+      const int g = 2 * ks + kh;          // (c, ky) group
+      const _Float16* w = p.W + (size_t)(h * 32 + px) * 294 + g * 7;   // c*49 + ky*7 == g*7
+#pragma unroll
+      for (int e = 0; e < 7; ++e) wf[h][ks][e] = w[e];
+      wf[h][ks][7] = (_Float16)0.f;
     }
-  }
 
   const int band_px = C1_ROWS * p.Wout;
   const int tiles = (band_px + 31) >> 5;
   const int row_bytes = p.PW * 2;
   const int Hp = p.Hout + 2 * p.pad, Wp = p.Wout + 2 * p.pad;
 
-  int band = blockIdx.x;
-  if (band < p.total_bands) c1_stage(p, band, patch0, tid);
-  int cur = 0;
-  for (; band < p.total_bands; band += gridDim.x, cur ^= 1) {
+  for (int band = blockIdx.x; band < p.total_bands; band += gridDim.x) {
+    c1_stage(p, band, patch, tid);
     __builtin_amdgcn_s_waitcnt(0);     // this band's patch has landed (own DMA) ...
-    __syncthreads();                   // ... and everyone's; everyone is also done reading the other buffer
-    unsigned char* patch = cur ? patch1 : patch0;
-    const int nxt = band + gridDim.x;
-    if (nxt < p.total_bands) c1_stage(p, nxt, cur ? patch0 : patch1, tid);
+    __syncthreads();                   // ... and everyone's
     const int b = band / p.bands_per_image;
     const int oy0 = (band - b * p.bands_per_image) * C1_ROWS;
-    for (int tile = tslot; tile < tiles; tile += 4) {
+    for (int tile = wid; tile < tiles; tile += C1_WAVES) {
       int t = tile * 32 + px;
       t = t < band_px ? t : band_px - 1;
       const int oyl = t / p.Wout, ox = t - oyl * p.Wout;
       // lane base: row 2*oyl of channel 0, dword (ox + 2) of the row  [element 2*ox + 5 = image x 2*ox - 3]
-      const unsigned char* lb = patch + (size_t)(2 * oyl) * row_bytes + (ox + 2) * 4;
-      float16_ acc;
+      const int lb = (2 * oyl) * row_bytes + (ox + 2) * 4;         // byte offset inside the patch (= inside smem)
+      float16_ acc0, acc1;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+      // B fragment of a lane = 8 consecutive input pixels starting at an odd element: five dwords, shifted by 16 bits.
+      // The dwords of k-step ks+1 are requested before the MFMAs of k-step ks.
+      unsigned int d[2][5];
+      // group g = 2*ks + kh -> patch row (g / 7) * C1_PR + g % 7: the kh = 1 half of the wave reads the row of group
+      // 2*ks + 1, which is 1 row further, or 15 rows where (c, ky = 6) is followed by (c + 1, ky = 0)
+      const int lb1 = lb + kh * row_bytes;
+      const int lb15 = lb + kh * 15 * row_bytes;
+      auto bread = [&](int ks, int slot) {
+        const int g0 = 2 * ks;
+        const int off0 = (g0 / 7) * C1_PR + (g0 % 7);
+        int a = ((g0 % 7) == 6 ? lb15 : lb1) + off0 * row_bytes;
+        asm volatile("" : "+v"(a));               // one address at a time: 21 hoisted addresses would not fit the register file
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(smem + a);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) d[slot][i] = src[i];
+      };
+      bread(0, 0);
 #pragma unroll
       for (int ks = 0; ks < C1_KS; ++ks) {
-        // group g = 2*ks + kh -> (c, ky) = (g / 7, g % 7); both candidates are compile-time constants
-        const int g0 = 2 * ks, g1 = 2 * ks + 1;
-        const int off0 = ((g0 / 7) * C1_PR + (g0 % 7)), off1 = ((g1 / 7) * C1_PR + (g1 % 7));
-        const unsigned int* d = reinterpret_cast<const unsigned int*>(lb + (size_t)(kh ? off1 : off0) * row_bytes);
-        const unsigned int d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+        if (ks + 1 < C1_KS) bread(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);         // keep the requests in front of this k-step's MFMAs
+        const unsigned int* dd = d[ks & 1];
         uint4_ fv;
-        fv[0] = __builtin_amdgcn_alignbit(d1, d0, 16);
-        fv[1] = __builtin_amdgcn_alignbit(d2, d1, 16);
-        fv[2] = __builtin_amdgcn_alignbit(d3, d2, 16);
-        fv[3] = __builtin_amdgcn_alignbit(d4, d3, 16);
+        fv[0] = __builtin_amdgcn_alignbit(dd[1], dd[0], 16);
+        fv[1] = __builtin_amdgcn_alignbit(dd[2], dd[1], 16);
+        fv[2] = __builtin_amdgcn_alignbit(dd[3], dd[2], 16);
+        fv[3] = __builtin_amdgcn_alignbit(dd[4], dd[3], 16);
         const half8 fb = __builtin_bit_cast(half8, fv);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], fb, acc, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][ks], fb, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][ks], fb, acc1, 0, 0, 0);
       }
       // ---- epilogue: fp16(conv) + bias -> fp16 -> BN -> fp16 -> ReLU (the autocast op sequence of
-      //      nn.Conv2d / nn.BatchNorm2d / nn.ReLU), transpose through the wave-private tile (32 px x 64 B), 16-byte stores
+      //      nn.Conv2d / nn.BatchNorm2d / nn.ReLU), transpose through the wave-private tile (32 px x 128 B), 16-byte stores
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        // packed fp16 math where it is exact (see igemm_epilogue.h): conv -> fp16, + bias as an IEEE half add, BatchNorm
-        // as an fp32 FMA rounded to fp16, ReLU on the packed halves
-        typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
-        half2_ t01 = {(_Float16)acc[g4 * 4 + 0], (_Float16)acc[g4 * 4 + 1]};
-        half2_ t23 = {(_Float16)acc[g4 * 4 + 2], (_Float16)acc[g4 * 4 + 3]};
-        t01 = t01 + bi2[g4][0];
-        t23 = t23 + bi2[g4][1];
-        half4 v;
-        if (has_bn) {
-          v[0] = (_Float16)fmaf((float)t01[0], sc[g4][0], sh[g4][0]);
-          v[1] = (_Float16)fmaf((float)t01[1], sc[g4][1], sh[g4][1]);
-          v[2] = (_Float16)fmaf((float)t23[0], sc[g4][2], sh[g4][2]);
-          v[3] = (_Float16)fmaf((float)t23[1], sc[g4][3], sh[g4][3]);
-        } else {
-          v[0] = t01[0]; v[1] = t01[1]; v[2] = t23[0]; v[3] = t23[1];
+      for (int h = 0; h < 2; ++h) {
+        const float16_& acc = h ? acc1 : acc0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          // packed fp16 math where it is exact (see igemm_epilogue.h): conv -> fp16, + bias as an IEEE half add, BatchNorm
+          // as an fp32 FMA rounded to fp16, ReLU on the packed halves
+          typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+          typedef float float4_ __attribute__((ext_vector_type(4)));
+          const int chn = h * 32 + 8 * g4 + 4 * kh;        // first of this lane's 4 consecutive channels
+          const float4_ bi = *reinterpret_cast<const float4_*>(vec + chn);
+          half2_ t01 = {(_Float16)acc[g4 * 4 + 0], (_Float16)acc[g4 * 4 + 1]};
+          half2_ t23 = {(_Float16)acc[g4 * 4 + 2], (_Float16)acc[g4 * 4 + 3]};
+          t01 = t01 + half2_{(_Float16)bi[0], (_Float16)bi[1]};
+          t23 = t23 + half2_{(_Float16)bi[2], (_Float16)bi[3]};
+          half4 v;
+          if (has_bn) {
+            const float4_ sc = *reinterpret_cast<const float4_*>(vec + 64 + chn);
+            const float4_ sh = *reinterpret_cast<const float4_*>(vec + 128 + chn);
+            v[0] = (_Float16)fmaf((float)t01[0], sc[0], sh[0]);
+            v[1] = (_Float16)fmaf((float)t01[1], sc[1], sh[1]);
+            v[2] = (_Float16)fmaf((float)t23[0], sc[2], sh[2]);
+            v[3] = (_Float16)fmaf((float)t23[1], sc[3], sh[3]);
+          } else {
+            v[0] = t01[0]; v[1] = t01[1]; v[2] = t23[0]; v[3] = t23[1];
+          }
+          v = __builtin_elementwise_max(v, half4{0, 0, 0, 0});
+          const int chunk = (chn >> 3) ^ (px & 7);         // 8 chunks of 16 B per pixel row
+          *reinterpret_cast<half4*>(etile + px * 128 + (chunk << 4) + ((chn & 4) << 1)) = v;
         }
-        v = __builtin_elementwise_max(v, half4{0, 0, 0, 0});
-        const int chl = 8 * g4 + 4 * kh;                 // channel within this wave's 32
-        const int chunk = (chl >> 3) ^ (px & 3);
-        *reinterpret_cast<half4*>(etile + px * 64 + (chunk << 4) + ((chl & 4) << 1)) = v;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < 4; ++it) {
         const int qd = lane + 64 * it;
-        const int pl = qd >> 2, chunk = qd & 3;
+        const int pl = qd >> 3, chunk = qd & 7;
         const int tt = tile * 32 + pl;
-        const half8 v = *reinterpret_cast<const half8*>(etile + pl * 64 + ((chunk ^ (pl & 3)) << 4));
+        const half8 v = *reinterpret_cast<const half8*>(etile + pl * 128 + ((chunk ^ (pl & 7)) << 4));
         if (tt < band_px) {
           const int oyy = oy0 + tt / p.Wout, oxx = tt % p.Wout;
           if (oyy < p.Hout)
-            *reinterpret_cast<half8*>(p.Y + (((size_t)b * Hp + oyy + p.pad) * Wp + oxx + p.pad) * 64 + hsel * 32 + chunk * 8) = v;
+            *reinterpret_cast<half8*>(p.Y + (((size_t)b * Hp + oyy + p.pad) * Wp + oxx + p.pad) * 64 + chunk * 8) = v;
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();                   // everyone is done with the patch before the next band overwrites it
   }
 }
 
@@ -205,7 +221,7 @@ extern "C" int fp_conv7x7s2_bn_relu_fwd(const void* x, const void* w, const floa
   p.total_bands = B * p.bands_per_image;
   p.PW = Win + 16;
   const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;
-  const size_t lds = 2 * (size_t)patch_bytes + 8 * 2048;
+  const size_t lds = (size_t)patch_bytes + C1_VEC_BYTES + C1_WAVES * C1_ETILE;
   if (lds > 160 * 1024) {
     fp_set_error("fp_conv7x7s2_bn_relu_fwd: input width %d needs %zu bytes of LDS", Win, lds);
     return FP_ERR_UNSUPPORTED;
@@ -222,7 +238,7 @@ extern "C" int fp_conv7x7s2_bn_relu_fwd(const void* x, const void* w, const floa
     n_cu[dev & 63] = prop.multiProcessorCount;
   }
   FP_SET_MAX_LDS(k_conv7x7s2_nhwc, 160 * 1024);
-  const int grid = p.total_bands < n_cu[dev & 63] ? p.total_bands : n_cu[dev & 63];
+  const int grid = p.total_bands < 2 * n_cu[dev & 63] ? p.total_bands : 2 * n_cu[dev & 63];
   hipLaunchKernelGGL(k_conv7x7s2_nhwc, dim3(grid), dim3(C1_THREADS), lds, (hipStream_t)stream, p);
   FP_CHECK_LAUNCH("fp_conv7x7s2_bn_relu_fwd");
   return FP_OK;

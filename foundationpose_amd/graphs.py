@@ -3,9 +3,9 @@
 `FoundationPose.track_one` (estimater.py:250-268) is, per frame: depth erosion -> bilateral filter -> back-projection
 -> `iteration` x (crop windows -> rasterise -> observed crop -> RefineNet -> pose update).  Shapes are static (frame
 size, number of hypotheses, iteration count), only values change, and every entry point of libfp_amd.so enqueues on
-the caller's stream without allocating or synchronising, so the whole frame is captured ONCE into a hipGraph (through
+the caller's stream without allocating or synchronising, so the whole frame is captured ONCE into hipGraphs (through
 torch.cuda.CUDAGraph, which also owns the private memory pool of the intermediate tensors) and replayed per frame:
-about 100 kernel launches per refine iteration collapse into one graph launch, and the pose stays on the device
+about 100 kernel launches per refine iteration collapse into a few graph launches, and the pose stays on the device
 between frames (the reference does a .cpu()/.cuda() round trip and an empty_cache() per frame,
 estimater.py:263, predict_pose_refine.py:237).
 """
@@ -17,8 +17,15 @@ from .Utils import get_mesh_handle
 
 
 class GraphedTracker:
-    """Static-shape tracker: `step(rgb, depth[, poses])` -> refined poses (N,4,4) on the device (a view of a static
-    buffer, valid until the next call).  With `poses=None` the previous output is the next input (tracking)."""
+    """Static-shape tracker: `step(rgb, depth[, poses])` -> refined poses (N,4,4) on the device (a static buffer, valid
+    until the next call).  With `poses=None` the previous output is the next input (tracking).
+
+    The frame is captured as 1 + k LINEAR graphs: the depth pre-processing, and the whole refine loop of each of the k
+    hypothesis sub-batches of the refiner (overlap.py).  A replay launches the first on the caller's stream and the k part
+    graphs on k streams forked from / joined into it.  (One graph with k parallel branches would be the obvious
+    alternative; on ROCm 7.2 its replay occasionally returned poses that differ from the eager result although every
+    stage of it, captured alone with the same two branches, is exact -- scripts/dbg_streams*.py -- so parallelism stays
+    between graphs, where ordering is ordinary stream semantics.)"""
 
     def __init__(self, refiner, mesh_tensors, mesh_diameter, K, H, W, n_hyp=1, iteration=2, device=None):
         self.refiner = refiner
@@ -30,26 +37,44 @@ class GraphedTracker:
         self.rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=self.dev)
         self.depth = torch.zeros((H, W), dtype=torch.float32, device=self.dev)
         self.poses_in = torch.eye(4, device=self.dev).repeat(self.N, 1, 1).contiguous()
-        # everything the captured kernels address by raw pointer and that is not allocated inside the capture belongs to
-        # the tracker: the rasteriser scratch here, the encoder's activation buffers by key in the plan (never dropped)
+        # everything the captured kernels address by raw pointer and that is not allocated inside a capture belongs to
+        # the tracker: the outputs and one rasteriser scratch per part here, the encoder's activation sets by
+        # (batch, H, W, slot) in the plan (never dropped)
         oh, ow = int(refiner.cfg["input_resize"][0]), int(refiner.cfg["input_resize"][1])
-        # (one scratch per concurrently running sub-batch of the refiner, overlap.py)
+        self.parts = refiner.sub.parts(self.N)
         self.workspace = [torch.empty(max(16, ops.workspace_bytes(b - a, self.handle.V, self.handle.T, oh, ow)),
-                                      dtype=torch.uint8, device=self.dev) for a, b in refiner.sub.parts(self.N)]
-        self.poses_out = None
-        self.graph = None
+                                      dtype=torch.uint8, device=self.dev) for a, b in self.parts]
+        self.outs = refiner.alloc_outputs(self.N, self.dev) + (self.R,)
+        self.poses_out = self.outs[0]
+        self.xyz = None
+        self.g_pre, self.g_part = None, []
+        self._have_output = False
+
+    def _pre(self):
+        d = ops.bilateral_filter_depth(ops.erode_depth(self.depth, radius=2), radius=2)
+        return ops.depth_to_xyz(d, self.K, zfar=float("inf"), f64_internal=False)     # depth2xyzmap_batch variant
+
+    def _part(self, h, xyz):
+        self.refiner.refine_part(h, self.parts[h], self.rgb, xyz, self.poses_in, self.K, self.H, self.W, self.handle,
+                                 self.diameter, range(self.R), self.outs, self.workspace[h])
 
     def _body(self):
-        d = ops.bilateral_filter_depth(ops.erode_depth(self.depth, radius=2), radius=2)
-        xyz = ops.depth_to_xyz(d, self.K, zfar=float("inf"), f64_internal=False)     # depth2xyzmap_batch variant
-        poses, _, _ = self.refiner.refine_device(self.rgb, xyz, self.poses_in, self.K, self.H, self.W, self.handle,
-                                                 self.diameter, self.R, workspace=self.workspace)
-        return poses
+        """the frame without graphs: same launches, same streams"""
+        xyz = self._pre()
+        streams = self.refiner.sub.streams(self.dev, len(self.parts))
+        self.refiner.sub.fork(streams)
+        for h in range(len(self.parts)):
+            with torch.cuda.stream(streams[h]):
+                self._part(h, xyz)
+        self.refiner.sub.join(streams)
+        if self.R <= 0:
+            self.poses_out.copy_(self.poses_in)
+        return self.poses_out
 
     @torch.inference_mode()
     def capture(self):
         """two eager warm-up runs on a side stream (lazy one-time initialisation inside the library and in PyTorch),
-        then the capture"""
+        then the captures, one after the other"""
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
@@ -57,27 +82,48 @@ class GraphedTracker:
                 self._body()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.poses_out = self._body()
+        self.g_pre = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_pre):
+            self.xyz = self._pre()
+        self.g_part = []
+        for h in range(len(self.parts)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._part(h, self.xyz)
+            self.g_part.append(g)
         return self
+
+    def replay(self):
+        """one frame from the static inputs (rgb, depth, poses_in) into poses_out"""
+        self.g_pre.replay()
+        streams = self.refiner.sub.streams(self.dev, len(self.parts))
+        self.refiner.sub.fork(streams)
+        for h, g in enumerate(self.g_part):
+            with torch.cuda.stream(streams[h]):
+                g.replay()
+        self.refiner.sub.join(streams)
+        if self.R <= 0:
+            self.poses_out.copy_(self.poses_in)
+        return self.poses_out
 
     @torch.inference_mode()
     def step(self, rgb, depth, poses=None):
-        if self.graph is None:
+        if self.g_pre is None:
             self.capture()
         self.rgb.copy_(torch.as_tensor(rgb, device=self.dev), non_blocking=True)
         self.depth.copy_(torch.as_tensor(depth, device=self.dev), non_blocking=True)
         if poses is not None:
             self.poses_in.copy_(torch.as_tensor(poses, device=self.dev, dtype=torch.float32).reshape(self.N, 4, 4))
-        elif self.poses_out is not None:
+        elif self._have_output:
             self.poses_in.copy_(self.poses_out)
-        self.graph.replay()
-        return self.poses_out
+        else:
+            raise RuntimeError("GraphedTracker.step: no previous output to track from, pass poses")
+        self._have_output = True
+        return self.replay()
 
     @torch.inference_mode()
     def step_eager(self, rgb, depth, poses):
-        """the same frame without the graph (for A/B timing and the equality test)"""
+        """the same frame without the graphs (for A/B timing and the equality test)"""
         self.rgb.copy_(torch.as_tensor(rgb, device=self.dev))
         self.depth.copy_(torch.as_tensor(depth, device=self.dev))
         self.poses_in.copy_(torch.as_tensor(poses, device=self.dev, dtype=torch.float32).reshape(self.N, 4, 4))

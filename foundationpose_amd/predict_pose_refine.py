@@ -128,64 +128,82 @@ class PoseRefinePredictor:
             self._plan_dev = dev
         return self._plan
 
-    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, workspace=None):
-        """The refine loop on device tensors only (predict_pose_refine.py:182-235): per iteration fp_crop_windows ->
-        fp_render_crops (A) + fp_warp_crops (B) -> RefineNet plan -> fp_pose_update.  No host round trip, no host-side
-        tensor creation: the whole call is capturable in a hipGraph (foundationpose_amd/graphs.py), which then passes
-        its own rasteriser scratch: `workspace` = one uint8 tensor per part of `self.sub.parts(N)` (or a single tensor
-        when there is one part).  Hypotheses are independent through all iterations, so the parts run the whole loop on
-        concurrent streams (overlap.py) and are joined once at the end.
-        -> (poses (N,4,4), trans_delta (N,3) in metres, rot_mat_delta (N,3,3)) of the last iteration, as the reference
-        keeps them in last_trans_update / last_rot_update (predict_pose_refine.py:238-239)"""
-        plan = self.plan()
-        N = poses.shape[0]
-        dev = poses.device
+    def _loop_constants(self):
         oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
         tn = self.cfg["trans_normalizer"]
         tn = [float(tn)] * 3 if isinstance(tn, (int, float)) else [float(v) for v in tn]
-        normalize = bool(self.cfg["normalize_xyz"])
+        return oh, ow, tn, bool(self.cfg["normalize_xyz"])
+
+    def refine_part(self, slot, rows, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iterations, outs, workspace=None,
+                    state=None):
+        """Iterations `iterations` (a range) of the refine loop for the hypotheses rows=(a, b) of `poses`, on the CURRENT
+        stream, with the activation-buffer set `slot`: per iteration fp_crop_windows -> fp_render_crops (A) +
+        fp_warp_crops (B) -> RefineNet plan -> fp_pose_update.  outs = (poses_out (N,4,4), trans_delta (N,3), rot_delta
+        (N,3,3), n_iterations_total): the last iteration writes rows a..b of them.  state: what the previous call for this
+        part returned (None for the first iteration).  -> state"""
+        plan = self.plan()
+        a, b = rows
+        n = b - a
+        oh, ow, tn, normalize = self._loop_constants()
+        poses_out, trans_delta, rot_delta, total = outs
+        if state is None:
+            state = dict(P=poses[a:b], AB=torch.empty((2 * n, 6, oh, ow), dtype=plan.dtype, device=poses.device), raw=None)
+        for it in iterations:
+            last = it + 1 == total
+            P, AB = state["P"], state["AB"]
+            tf_to_crops, bbox2d = ops.crop_windows(P, K, mesh_diameter, self.cfg["crop_ratio"], (ow, oh))
+            if poses.shape[0] == 2:
+                # reference broadcasting quirk (SURVEY App. D.5): with exactly two poses transform_pts pairs pose i with
+                # corner i, so both hypotheses are rendered with [umin_0, vmin_0, umax_1, vmax_1]
+                bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
+            ops.render_crops(mesh_handle, P, bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter, xyz_thr=0.001,
+                             normalize_xyz=normalize, A_out=AB[:n], workspace=workspace)
+            ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops, K, P, mesh_diameter, ops.MODE_REFINE, normalize_xyz=normalize,
+                           out_hw=(oh, ow), B_out=AB[n:])
+            raw = plan(AB, slot=slot)
+            state["raw"] = raw
+            state["P"] = ops.pose_update(raw["trans"], raw["rot"], P, rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
+                                         trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
+                                         mesh_diameter=float(mesh_diameter), out=poses_out[a:b] if last else None,
+                                         trans_delta_out=trans_delta[a:b] if last else None,
+                                         rot_delta_out=rot_delta[a:b] if last else None, trans_rep=str(self.cfg["trans_rep"]), K=K,
+                                         tf_to_crops=tf_to_crops, input_w=float(self.cfg["input_resize"][0]))
+        return state
+
+    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, workspace=None):
+        """The refine loop on device tensors only (predict_pose_refine.py:182-235).  No host round trip, no host-side
+        tensor creation.  Hypotheses are independent through all iterations, so the parts of `self.sub.parts(N)` run the
+        whole loop as independent launch sequences on concurrent streams (overlap.py), issued iteration by iteration and
+        joined once at the end.  workspace: optional rasteriser scratch, one uint8 tensor per part.
+        -> (poses (N,4,4), trans_delta (N,3) in metres, rot_mat_delta (N,3,3)) of the last iteration, as the reference
+        keeps them in last_trans_update / last_rot_update (predict_pose_refine.py:238-239)"""
+        self.plan()
+        N = poses.shape[0]
+        dev = poses.device
         parts = self.sub.parts(N)
         if workspace is not None and torch.is_tensor(workspace):
-            if len(parts) != 1:
-                raise ValueError(f"refine_device: {len(parts)} parts need a list of {len(parts)} workspaces")
             workspace = [workspace]
-        poses_out = torch.empty((N, 4, 4), dtype=torch.float32, device=dev)
-        trans_delta = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        rot_delta = torch.empty((N, 3, 3), dtype=torch.float32, device=dev)
+        if workspace is not None and len(workspace) != len(parts):
+            raise ValueError(f"refine_device: {len(parts)} parts need {len(parts)} workspaces, got {len(workspace)}")
+        outs = self.alloc_outputs(N, dev) + (int(iteration),)
         if iteration <= 0:
-            poses_out.copy_(poses)
+            outs[0].copy_(poses)
         streams = self.sub.streams(dev, len(parts))
         self.sub.fork(streams)
-        P = [poses[a:b] for a, b in parts]
-        AB = [None] * len(parts)
-        raw = [None] * len(parts)
+        state = [None] * len(parts)
         for it in range(iteration):
-            last = it + 1 == iteration
-            for h, (a, b) in enumerate(parts):
-                n = b - a
+            for h, rows in enumerate(parts):
                 with torch.cuda.stream(streams[h]):
-                    if AB[h] is None:
-                        AB[h] = torch.empty((2 * n, 6, oh, ow), dtype=plan.dtype, device=dev)
-                    tf_to_crops, bbox2d = ops.crop_windows(P[h], K, mesh_diameter, self.cfg["crop_ratio"], (ow, oh))
-                    if N == 2:
-                        # reference broadcasting quirk (SURVEY App. D.5): with exactly two poses transform_pts pairs pose i
-                        # with corner i, so both hypotheses are rendered with [umin_0, vmin_0, umax_1, vmax_1]
-                        bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
-                    ops.render_crops(mesh_handle, P[h], bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
-                                     xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[h][:n],
-                                     workspace=None if workspace is None else workspace[h])
-                    ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops, K, P[h], mesh_diameter, ops.MODE_REFINE,
-                                   normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[h][n:])
-                    raw[h] = plan(AB[h], slot=h)
-                    P[h] = ops.pose_update(raw[h]["trans"], raw[h]["rot"], P[h], rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
-                                           trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
-                                           mesh_diameter=float(mesh_diameter), out=poses_out[a:b] if last else None,
-                                           trans_delta_out=trans_delta[a:b] if last else None,
-                                           rot_delta_out=rot_delta[a:b] if last else None, trans_rep=str(self.cfg["trans_rep"]), K=K,
-                                           tf_to_crops=tf_to_crops, input_w=float(self.cfg["input_resize"][0]))
+                    state[h] = self.refine_part(h, rows, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, range(it, it + 1),
+                                                outs, None if workspace is None else workspace[h], state[h])
         self.sub.join(streams)
-        self._raw_parts = raw          # raw network outputs of the last iteration (debugging / tests): last_raw_output
-        return poses_out, trans_delta, rot_delta
+        self._raw_parts = [None if st is None else st["raw"] for st in state]   # last_raw_output
+        return outs[:3]
+
+    @staticmethod
+    def alloc_outputs(N, dev):
+        return (torch.empty((N, 4, 4), dtype=torch.float32, device=dev), torch.empty((N, 3), dtype=torch.float32, device=dev),
+                torch.empty((N, 3, 3), dtype=torch.float32, device=dev))
 
     @property
     def last_raw_output(self):

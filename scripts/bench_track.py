@@ -1,6 +1,6 @@
 """BASELINE configs[4]: tracking mode -- a 1000-frame synthetic RGB-D sequence of a moving object,
-64 pose hypotheses per frame (perturbations of the previous frame's pose), 2 refine iterations, one captured hipGraph
-replay per frame (foundationpose_amd/graphs.py: depth erosion + bilateral filter + back-projection + 2 x (crop windows,
+64 pose hypotheses per frame (perturbations of the previous frame's pose), 2 refine iterations, captured hipGraphs
+replayed per frame (foundationpose_amd/graphs.py: depth erosion + bilateral filter + back-projection + 2 x (crop windows,
 rasteriser, observed crop, RefineNet, pose update)).  Every frame is different: its own GT pose on a smooth trajectory,
 rendered by the product's rasteriser, with its own noise / dropout; per frame the uint8 colour image, the float depth
 map and the 64 hypotheses are uploaded from pinned host memory (the H2D copies are inside the timed region).
@@ -73,10 +73,7 @@ def frame(f, graph=True):
     trk.rgb.copy_(rgb_u8)                                # u8 -> f32 on the device
     trk.depth.copy_(depth_h[f], non_blocking=True)       # H2D, 1.2 MB
     trk.poses_in.copy_(hyp_h[f], non_blocking=True)      # H2D, 4 KB
-    if graph:
-        trk.graph.replay()
-        return trk.poses_out
-    return trk._body()
+    return trk.replay() if graph else trk._body()
 
 
 res = {}
