@@ -1,21 +1,26 @@
 // Patch-embed convolution of both encoders (refine_network.py:38, score_network.py:37: ConvBNReLU(6 -> 64, 7x7,
-// stride 2, pad 3)) for gfx950, NHWC output.  HBM-bound by construction (0.48 GFLOP against 1.95 MB per pair of
-// images), so the kernel is organised around streaming:
+// stride 2, pad 3)) for gfx950, NHWC output.  By bytes it should be HBM-bound (0.48 GFLOP against 1.95 MB per pair of
+// images); measured (shader-clock phase timers of the profiling build, scripts/dbg_conv1.py, 504 images) it is bound by
+// latency chains inside a wave: 13 % issuing the patch DMA, 9 % waiting for it, 72 % in the k-loops and epilogues at
+// ~40 % MFMA occupancy (the LDS round trip of a B fragment is longer than the two MFMAs it feeds, and 168 of 255
+// registers hold weights, so the prefetch is one k-step deep).  0.22 ms for 504 images = 2.6 TB/s.
 //   * persistent workgroups of four waves, two per CU (61 KB of LDS each): while one waits for its input patch the other
-//     multiplies.  A wave owns a tile of 32 output pixels and ALL 64 output channels: the 64 x 294 weights are loaded
-//     ONCE, straight from the PyTorch (64, 6*7*7) layout, into MFMA A-fragments that live in registers for the whole
-//     launch (168 VGPRs), so every B-fragment read from LDS feeds two MFMAs (the first versions split the channels
-//     over two waves and read every fragment twice: LDS reads, not MFMA or HBM, set their pace)
-//     (k re-ordered as (c, ky, kx[8]) = 42 groups of 8 -> 21 k-steps of v_mfma_f32_32x32x16_f16; kx = 7 is a zero weight);
+//     multiplies.  A wave owns a tile of 32 output pixels and ALL 64 output channels: the 64 x 294 weights are staged
+//     ONCE per workgroup (coalesced, through LDS) from the PyTorch (64, 6*7*7) layout into MFMA A-fragments that live in
+//     registers for the whole launch (168 VGPRs), so every B-fragment read from LDS feeds two MFMAs
+//     (k re-ordered as (c, ky, [0, kx 0..6]) = 42 groups of 8 -> 21 k-steps of v_mfma_f32_32x32x16_f16; slot 0 is a zero weight);
 //   * work unit = (image, band of 8 output rows): its 6 x 21 x (W+16) input patch goes HBM -> LDS by
 //     global_load_lds_dwordx4 (zero padding comes from a 16-byte zero block, so the DMA stays lane-linear);
-//   * B-fragment of a lane = 8 consecutive input pixels of one (c, ky) row starting at 2*ox - 3: five conflict-free
-//     dword reads + four v_alignbit (the run starts on an odd element), requested one k-step ahead; no im2col, no index table;
-//   * D[channel][pixel] accumulators go through the reference's autocast op sequence -- conv output rounded to fp16,
-//     + bias (fp16), eval BatchNorm (fp32 statistics) rounded to fp16, ReLU -- are transposed through a wave-private
-//     swizzled LDS tile and leave as 16-byte stores: 128 contiguous bytes per pixel (all 64 channels).
+//   * B-fragment of a lane = the 8 consecutive input pixels 2*ox - 4 .. 2*ox + 3 of one (c, ky) row (the first one meets
+//     the zero weight): four conflict-free dword reads used as they are, requested one k-step ahead; no im2col, no
+//     index table, no per-k-step VALU work beyond one address add;
+//   * D[channel][pixel] accumulators are rounded to fp16 (the conv output of the autocast sequence), transposed through a
+//     wave-private swizzled LDS tile, and finished on the way out -- + bias (fp16), eval BatchNorm (fp32 FMA) -> fp16,
+//     ReLU -- where a lane always holds the same 8 channels, whose bias / scale / shift stay in registers; 16-byte
+//     stores, 128 contiguous bytes per pixel (all 64 channels).
 #include <hip/hip_fp16.h>
 #include "fp_common.h"
+#include "igemm_common.h"   // ig_fastdiv
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -29,10 +34,23 @@ typedef unsigned int uint4_ __attribute__((ext_vector_type(4)));
 #define C1_WAVES 4
 #define C1_THREADS (64 * C1_WAVES)
 #define C1_MAXW 256
-#define C1_VEC_BYTES (3 * 64 * 4)    // bias | BatchNorm scale | shift as fp32, in LDS
 #define C1_ETILE 4096                // wave-private 32 px x 64 ch transpose tile
 
 __device__ __attribute__((aligned(16))) const unsigned int c1_zero16[4] = {0u, 0u, 0u, 0u};
+
+#ifdef FP_PROFILE_BUILD
+// profiling build only: shader-clock time per phase, summed over the waves of a launch (scripts/dbg_conv1.py)
+__device__ unsigned long long c1_dbg[8];
+extern "C" int fp_dbg_conv1(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(c1_dbg), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c1_dbg), 8 * sizeof(unsigned long long));
+}
+#define C1_CLK(t) const unsigned long long t = __builtin_readcyclecounter()
+#define C1_ADD(i, a, b) c1_t[i] += (b) - (a)
+#else
+#define C1_CLK(t)
+#define C1_ADD(i, a, b)
+#endif
 
 struct Conv1Params {
   const _Float16* X;     // (B, 6, Hin, Win)
@@ -44,6 +62,8 @@ struct Conv1Params {
   int B, Hin, Win, Hout, Wout, pad;
   int bands_per_image, total_bands;
   int PW;                // patch row length in halves = Win + 16
+  unsigned mulC, shrC;   // n / (PW / 8)   (ig_fastdiv)
+  unsigned mulW, shrW;   // n / Wout
 };
 
 __device__ __forceinline__ void c1_stage(const Conv1Params& p, int band, unsigned char* patch, int tid) {
@@ -59,10 +79,10 @@ __device__ __forceinline__ void c1_stage(const Conv1Params& p, int band, unsigne
     const int ch = base + lane;
     const void* src = c1_zero16;
     if (ch < nchunks) {
-      const int q = ch % cpr, t = ch / cpr;
-      const int r = t % C1_PR, c = t / C1_PR;
+      const int t = ig_fastdiv(ch, p.mulC, p.shrC), q = ch - t * cpr;
+      const int c = (t * 3121) >> 16, r = t - c * C1_PR;       // t / 21 for t < 6 * 21
       const int iy = iy0 + r, ix = (q - 1) * 8;   // patch element x = image x + 8
-      if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) src = Xb + ((size_t)c * p.Hin + iy) * p.Win + ix;
+      if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) src = Xb + ((c * p.Hin + iy) * p.Win + ix);
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(patch + (size_t)base * 16), 16, 0, 0);
@@ -76,52 +96,75 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
   const int px = lane & 31, kh = lane >> 5;
   const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;  // DMA may overrun by < 64 chunks
   unsigned char* patch = smem;
-  float* vec = reinterpret_cast<float*>(smem + patch_bytes);          // [bias | scale | shift][64]
-  unsigned char* etile = smem + patch_bytes + C1_VEC_BYTES + wid * C1_ETILE;
+  unsigned char* etile = smem + patch_bytes + wid * C1_ETILE;
 
-  if (tid < 64) {
-    vec[tid] = p.bias ? p.bias[tid] : 0.f;
-    vec[64 + tid] = p.scale ? p.scale[tid] : 1.f;
-    vec[128 + tid] = p.scale ? p.shift[tid] : 0.f;
-  }
   const bool has_bn = p.scale != nullptr;
 
-  // ---- weights -> register-resident A fragments, both channel halves: wf[h][ks] = W[32 h + px][group 2*ks + kh][0..7]
+  // ---- weights -> register-resident A fragments, both channel halves: wf[h][ks] = W[32 h + px][group 2*ks + kh][0..7].
+  // The (64, 294) matrix comes in once per workgroup with coalesced 16-byte loads and is redistributed through LDS
+  // (the patch area, before the first band): gathering the fragments straight from global memory is 294 two-byte loads
+  // per lane at a lane stride of 588 B, ~9 k cache-line requests per wave, which cost a third of the whole launch.
+  {
+    constexpr int WCH = 64 * 294 * 2 / 16;            // 2352 16-byte chunks
+    for (int c = tid; c < WCH; c += C1_THREADS)
+      *reinterpret_cast<uint4_*>(smem + c * 16) = *reinterpret_cast<const uint4_*>(reinterpret_cast<const unsigned char*>(p.W) + c * 16);
+  }
+  __syncthreads();
   half8 wf[2][C1_KS];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int ks = 0; ks < C1_KS; ++ks) {
       const int g = 2 * ks + kh;          // (c, ky) group
-      const _Float16* w = p.W + (size_t)(h * 32 + px) * 294 + g * 7;   // c*49 + ky*7 == g*7
+      const _Float16* w = reinterpret_cast<const _Float16*>(smem) + (h * 32 + px) * 294 + g * 7;   // c*49 + ky*7 == g*7
 #pragma unroll
-      for (int e = 0; e < 7; ++e) wf[h][ks][e] = w[e];
-      wf[h][ks][7] = (_Float16)0.f;
+      for (int e = 0; e < 7; ++e) wf[h][ks][e + 1] = w[e];
+      wf[h][ks][0] = (_Float16)0.f;
     }
-
+  __syncthreads();                     // fragments are in registers before the staging area is reused
+  // output side: this lane's 8 channels (16-byte chunk lane & 7 of a pixel's 64)
+  const int ochunk = lane & 7;
+  half8 obias;
+  float osc[8], osh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    obias[e] = (_Float16)(p.bias ? p.bias[ochunk * 8 + e] : 0.f);
+    osc[e] = p.scale ? p.scale[ochunk * 8 + e] : 1.f;
+    osh[e] = p.scale ? p.shift[ochunk * 8 + e] : 0.f;
+  }
   const int band_px = C1_ROWS * p.Wout;
   const int tiles = (band_px + 31) >> 5;
   const int row_bytes = p.PW * 2;
   const int Hp = p.Hout + 2 * p.pad, Wp = p.Wout + 2 * p.pad;
 
+#ifdef FP_PROFILE_BUILD
+  unsigned long long c1_t[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  C1_CLK(tk_all);
   for (int band = blockIdx.x; band < p.total_bands; band += gridDim.x) {
+    C1_CLK(ta);
     c1_stage(p, band, patch, tid);
+    C1_CLK(tb);
     __builtin_amdgcn_s_waitcnt(0);     // this band's patch has landed (own DMA) ...
     __syncthreads();                   // ... and everyone's
+    C1_CLK(tc);
+    C1_ADD(0, ta, tb); C1_ADD(1, tb, tc);
     const int b = band / p.bands_per_image;
     const int oy0 = (band - b * p.bands_per_image) * C1_ROWS;
     for (int tile = wid; tile < tiles; tile += C1_WAVES) {
       int t = tile * 32 + px;
       t = t < band_px ? t : band_px - 1;
-      const int oyl = t / p.Wout, ox = t - oyl * p.Wout;
-      // lane base: row 2*oyl of channel 0, dword (ox + 2) of the row  [element 2*ox + 5 = image x 2*ox - 3]
+      const int oyl = ig_fastdiv(t, p.mulW, p.shrW), ox = t - oyl * p.Wout;
+      // lane base: row 2*oyl of channel 0, dword (ox + 2) of the row  [element 2*ox + 4 = image x 2*ox - 4]
       const int lb = (2 * oyl) * row_bytes + (ox + 2) * 4;         // byte offset inside the patch (= inside smem)
       float16_ acc0, acc1;
+      C1_CLK(tk0);
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-      // B fragment of a lane = 8 consecutive input pixels starting at an odd element: five dwords, shifted by 16 bits.
-      // The dwords of k-step ks+1 are requested before the MFMAs of k-step ks.
-      unsigned int d[2][5];
+      // B fragment of a lane = the 8 consecutive input pixels 2*ox - 4 .. 2*ox + 3 of one (c, ky) row: four dwords, used
+      // as they are (the zero weight of the k-group sits in FRONT of the seven taps, which makes the run start on an even
+      // element).  The dwords of k-step ks+1 are requested before the MFMAs of k-step ks.
+      unsigned int d[2][4];
       // group g = 2*ks + kh -> patch row (g / 7) * C1_PR + g % 7: the kh = 1 half of the wave reads the row of group
       // 2*ks + 1, which is 1 row further, or 15 rows where (c, ky = 6) is followed by (c + 1, ky = 0)
       const int lb1 = lb + kh * row_bytes;
@@ -133,7 +176,7 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
         asm volatile("" : "+v"(a));               // one address at a time: 21 hoisted addresses would not fit the register file
         const unsigned int* src = reinterpret_cast<const unsigned int*>(smem + a);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) d[slot][i] = src[i];
+        for (int i = 0; i < 4; ++i) d[slot][i] = src[i];
       };
       bread(0, 0);
 #pragma unroll
@@ -141,66 +184,73 @@ __global__ __launch_bounds__(C1_THREADS, 2) void k_conv7x7s2_nhwc(Conv1Params p)
         if (ks + 1 < C1_KS) bread(ks + 1, (ks + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);         // keep the requests in front of this k-step's MFMAs
         const unsigned int* dd = d[ks & 1];
-        uint4_ fv;
-        fv[0] = __builtin_amdgcn_alignbit(dd[1], dd[0], 16);
-        fv[1] = __builtin_amdgcn_alignbit(dd[2], dd[1], 16);
-        fv[2] = __builtin_amdgcn_alignbit(dd[3], dd[2], 16);
-        fv[3] = __builtin_amdgcn_alignbit(dd[4], dd[3], 16);
+        const uint4_ fv = {dd[0], dd[1], dd[2], dd[3]};
         const half8 fb = __builtin_bit_cast(half8, fv);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][ks], fb, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][ks], fb, acc1, 0, 0, 0);
       }
-      // ---- epilogue: fp16(conv) + bias -> fp16 -> BN -> fp16 -> ReLU (the autocast op sequence of
-      //      nn.Conv2d / nn.BatchNorm2d / nn.ReLU), transpose through the wave-private tile (32 px x 128 B), 16-byte stores
+#ifdef FP_PROFILE_BUILD
+      asm volatile("" : "+v"(acc0), "+v"(acc1));
+#endif
+      C1_CLK(tk1);
+      C1_ADD(2, tk0, tk1);
+      // ---- epilogue.  The conv output is rounded to fp16 (first rounding point of the autocast sequence) and transposed
+      // through the wave-private tile (32 px x 128 B); the rest of the sequence -- + bias (fp16), eval BatchNorm (fp32 FMA)
+      // -> fp16, ReLU -- runs on the way out, where a lane always holds the SAME 8 channels (chunk = lane & 7): their
+      // bias / scale / shift live in registers for the whole launch (fetching the vectors of the accumulator layout from
+      // LDS per tile was a chain of ~24 dependent LDS round trips: half of the kernel's time)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float16_& acc = h ? acc1 : acc0;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          // packed fp16 math where it is exact (see igemm_epilogue.h): conv -> fp16, + bias as an IEEE half add, BatchNorm
-          // as an fp32 FMA rounded to fp16, ReLU on the packed halves
-          typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
-          typedef float float4_ __attribute__((ext_vector_type(4)));
           const int chn = h * 32 + 8 * g4 + 4 * kh;        // first of this lane's 4 consecutive channels
-          const float4_ bi = *reinterpret_cast<const float4_*>(vec + chn);
-          half2_ t01 = {(_Float16)acc[g4 * 4 + 0], (_Float16)acc[g4 * 4 + 1]};
-          half2_ t23 = {(_Float16)acc[g4 * 4 + 2], (_Float16)acc[g4 * 4 + 3]};
-          t01 = t01 + half2_{(_Float16)bi[0], (_Float16)bi[1]};
-          t23 = t23 + half2_{(_Float16)bi[2], (_Float16)bi[3]};
-          half4 v;
-          if (has_bn) {
-            const float4_ sc = *reinterpret_cast<const float4_*>(vec + 64 + chn);
-            const float4_ sh = *reinterpret_cast<const float4_*>(vec + 128 + chn);
-            v[0] = (_Float16)fmaf((float)t01[0], sc[0], sh[0]);
-            v[1] = (_Float16)fmaf((float)t01[1], sc[1], sh[1]);
-            v[2] = (_Float16)fmaf((float)t23[0], sc[2], sh[2]);
-            v[3] = (_Float16)fmaf((float)t23[1], sc[3], sh[3]);
-          } else {
-            v[0] = t01[0]; v[1] = t01[1]; v[2] = t23[0]; v[3] = t23[1];
-          }
-          v = __builtin_elementwise_max(v, half4{0, 0, 0, 0});
+          const half4 v = {(_Float16)acc[g4 * 4 + 0], (_Float16)acc[g4 * 4 + 1], (_Float16)acc[g4 * 4 + 2], (_Float16)acc[g4 * 4 + 3]};
           const int chunk = (chn >> 3) ^ (px & 7);         // 8 chunks of 16 B per pixel row
           *reinterpret_cast<half4*>(etile + px * 128 + (chunk << 4) + ((chn & 4) << 1)) = v;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      half8 ov[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int qd = lane + 64 * it;
-        const int pl = qd >> 3, chunk = qd & 7;
-        const int tt = tile * 32 + pl;
-        const half8 v = *reinterpret_cast<const half8*>(etile + pl * 128 + ((chunk ^ (pl & 7)) << 4));
-        if (tt < band_px) {
-          const int oyy = oy0 + tt / p.Wout, oxx = tt % p.Wout;
-          if (oyy < p.Hout)
-            *reinterpret_cast<half8*>(p.Y + (((size_t)b * Hp + oyy + p.pad) * Wp + oxx + p.pad) * 64 + chunk * 8) = v;
+        const int pl = (lane >> 3) + 8 * it;
+        ov[it] = *reinterpret_cast<const half8*>(etile + pl * 128 + ((ochunk ^ (pl & 7)) << 4));
+      }
+      // first pixel of the tile (wave-uniform), then 8 pixels further per iteration
+      const int t0 = tile * 32 + (lane >> 3);
+      const int oyt0 = ig_fastdiv(t0, p.mulW, p.shrW);
+      int oyy = oy0 + oyt0, oxx = t0 - oyt0 * p.Wout;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        half8 v = ov[it] + obias;                          // IEEE half add == fp32 add of two halves rounded once
+        if (has_bn) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (_Float16)fmaf((float)v[e], osc[e], osh[e]);
         }
+        v = __builtin_elementwise_max(v, half8{0, 0, 0, 0, 0, 0, 0, 0});
+        if (tile * 32 + (lane >> 3) + 8 * it < band_px && oyy < p.Hout)
+          *reinterpret_cast<half8*>(p.Y + ((size_t)((b * Hp + oyy + p.pad) * Wp + oxx + p.pad)) * 64 + ochunk * 8) = v;
+        oxx += 8;
+        while (oxx >= p.Wout) { oxx -= p.Wout; ++oyy; }
       }
       __builtin_amdgcn_wave_barrier();
+      C1_CLK(tk2);
+      C1_ADD(3, tk1, tk2);
     }
+    C1_CLK(td);
     __syncthreads();                   // everyone is done with the patch before the next band overwrites it
+    C1_CLK(te);
+    C1_ADD(4, td, te);
   }
+#ifdef FP_PROFILE_BUILD
+  if (lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&c1_dbg[i], c1_t[i]);
+    atomicAdd(&c1_dbg[5], __builtin_readcyclecounter() - tk_all);
+    atomicAdd(&c1_dbg[6], 1ull);
+  }
+#endif
 }
 
 extern "C" int fp_conv7x7s2_bn_relu_fwd(const void* x, const void* w, const float* bias, const float* bn_scale,
@@ -220,8 +270,11 @@ extern "C" int fp_conv7x7s2_bn_relu_fwd(const void* x, const void* w, const floa
   FP_REQUIRE((long long)B * p.bands_per_image < (1ll << 31), "fp_conv7x7s2_bn_relu_fwd: batch too large");
   p.total_bands = B * p.bands_per_image;
   p.PW = Win + 16;
+  ig_fastdiv_init(p.PW >> 3, &p.mulC, &p.shrC);
+  ig_fastdiv_init(p.Wout, &p.mulW, &p.shrW);
   const int patch_bytes = ((C1_CIN * C1_PR * p.PW * 2 + 64 * 16 + 1023) / 1024) * 1024;
-  const size_t lds = (size_t)patch_bytes + C1_VEC_BYTES + C1_WAVES * C1_ETILE;
+  size_t lds = (size_t)patch_bytes + C1_WAVES * C1_ETILE;
+  if (lds < 64 * 294 * 2) lds = 64 * 294 * 2;     // the weight staging area of the prologue
   if (lds > 160 * 1024) {
     fp_set_error("fp_conv7x7s2_bn_relu_fwd: input width %d needs %zu bytes of LDS", Win, lds);
     return FP_ERR_UNSUPPORTED;
