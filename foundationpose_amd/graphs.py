@@ -22,10 +22,8 @@ class GraphedTracker:
 
     The frame is captured as 1 + k LINEAR graphs: the depth pre-processing, and the whole refine loop of each of the k
     hypothesis sub-batches of the refiner (overlap.py).  A replay launches the first on the caller's stream and the k part
-    graphs on k streams forked from / joined into it.  (One graph with k parallel branches would be the obvious
-    alternative; on ROCm 7.2 its replay occasionally returned poses that differ from the eager result although every
-    stage of it, captured alone with the same two branches, is exact -- scripts/dbg_streams*.py -- so parallelism stays
-    between graphs, where ordering is ordinary stream semantics.)"""
+    graphs on k streams forked from / joined into it, so the overlap between sub-batches is ordinary stream semantics and
+    every graph stays a simple chain."""
 
     def __init__(self, refiner, mesh_tensors, mesh_diameter, K, H, W, n_hyp=1, iteration=2, device=None):
         self.refiner = refiner

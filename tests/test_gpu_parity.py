@@ -615,3 +615,105 @@ def test_attention_kernel_matches_fp32_softmax_attention(dev, B, S):
     assert out.shape == ref.shape and out.dtype == torch.float16
     err = (out.float() - ref).abs().max().item()
     assert err < 4e-3, err
+
+
+def test_rasteriser_is_exact_next_to_a_gemm_on_another_stream(scene, dev, gmesh):
+    """Regression for a gfx950 finding (csrc/Makefile, -fno-slp-vectorize): with packed-fp32 VALU instructions in its
+    shading phase, k_raster returned wrong values in lanes 48-63 of a wave (16-pixel runs shaded at a neighbouring pixel
+    centre) in ~90 % of the launches that overlapped an MFMA kernel of another stream -- a rocBLAS GEMM is enough.  The
+    sub-batch streams of overlap.py make that overlap the normal case."""
+    from foundationpose_amd import ops
+    from foundationpose_amd.Utils import get_mesh_handle
+    h = get_mesh_handle(gmesh)
+    n = 38
+    P = torch.as_tensor(scene["poses"][:n], device=dev)
+    K, diam = scene["K"], scene["diameter"]
+    _, bb = ops.crop_windows(P, K, diam, 1.2, (160, 160))
+    A = torch.zeros((n, 6, 160, 160), dtype=torch.float16, device=dev)
+    ws = torch.empty(max(16, ops.workspace_bytes(n, h.V, h.T, 160, 160)), dtype=torch.uint8, device=dev)
+    x = torch.randn((14800, 512), device=dev, dtype=torch.float16)
+    w = torch.randn((512, 512), device=dev, dtype=torch.float16)
+    y = torch.empty((14800, 512), device=dev, dtype=torch.float16)
+    side = torch.cuda.Stream(device=dev)
+
+    def render():
+        return ops.render_crops(h, P, bb, K, 480, 640, out_hw=(160, 160), mesh_diameter=diam, xyz_thr=0.001, normalize_xyz=True,
+                                A_out=A, workspace=ws, want=("A", "zbuf", "tri_id"))
+    base = {k: v.clone() for k, v in render().items()}
+    torch.cuda.synchronize()
+    bad = 0
+    for rep in range(40):
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        r = render()                                   # the rasteriser first, the GEMM arrives while it runs
+        with torch.cuda.stream(side):
+            torch.matmul(x, w.t(), out=y)
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        bad += int(any(not torch.equal(r[k], base[k]) for k in r))
+    assert bad == 0, f"{bad} of 40 overlapped launches differ from the launch that ran alone"
+
+
+def test_network_kernels_write_only_their_outputs(dev):
+    """outputs placed inside a poisoned arena: ragged GEMM / conv shapes (partial tiles), tokens + positional output,
+    attention -- no byte outside the output tensors changes"""
+    import ctypes as C
+    from foundationpose_amd import ops, _lib
+    G = 1 << 20
+
+    def arena(nbytes):
+        a = torch.full((G + nbytes + G,), 0x5A, dtype=torch.uint8, device=dev)
+        return a, a[G:G + nbytes]
+
+    def intact(a, nbytes):
+        return bool((a[:G] == 0x5A).all()) and bool((a[G + nbytes:] == 0x5A).all())
+    g = torch.Generator(device="cpu").manual_seed(0)
+    Gm, Gi = ops.IgemmGeom.matrix, ops.IgemmGeom.image
+    for M in (14800, 50400, 127, 129):
+        for N in (512, 1536):
+            x = (torch.randn((M, 512), generator=g) * 0.1).half().to(dev)
+            w = (torch.randn((N, 512), generator=g) * 0.05).half().to(dev)
+            a, yv = arena(M * N * 2)
+            ops.igemm_f16(x, Gm(512), w, torch.zeros(N, device=dev), yv.view(torch.float16).reshape(M, N), Gm(N), M, N, 512, 1, relu=False)
+            torch.cuda.synchronize()
+            assert intact(a, M * N * 2), ("linear", M, N)
+    for (Bn, H, Cin, Cout, stride) in ((37, 40, 128, 128, 1), (19, 40, 256, 256, 1), (37, 20, 512, 512, 1), (19, 40, 256, 512, 2), (21, 80, 64, 128, 2)):
+        Ho = H // stride
+        xin = torch.zeros((Bn, H + 2, H + 2, Cin), dtype=torch.float16, device=dev)
+        xin[:, 1:-1, 1:-1] = (torch.randn((Bn, H, H, Cin), generator=g) * 0.1).half().to(dev)
+        w = (torch.randn((Cout, 9 * Cin), generator=g) * 0.02).half().to(dev)
+        nb = Bn * (Ho + 2) * (Ho + 2) * Cout * 2
+        a, yv = arena(nb)
+        yv.zero_()
+        ops.igemm_f16(xin, Gi(Ho, Ho, 1, Cin, stride=stride, offset=0), w, torch.zeros(Cout, device=dev),
+                      yv.view(torch.float16).reshape(Bn, Ho + 2, Ho + 2, Cout), Gi(Ho, Ho, 1, Cout), Bn * Ho * Ho, Cout, Cin, 9,
+                      relu=True, conv_rounding=True)
+        torch.cuda.synchronize()
+        assert intact(a, nb), ("conv3x3", Bn, H, Cin, Cout, stride)
+        if stride == 1 and Cout == 512:
+            nb2 = Bn * Ho * Ho * Cout * 2
+            a1, t1 = arena(nb2)
+            a2, t2 = arena(nb2)
+            ops.igemm_f16(xin, Gi(Ho, Ho, 1, Cin, stride=1, offset=0), w, torch.zeros(Cout, device=dev),
+                          t1.view(torch.float16).reshape(Bn, Ho * Ho, Cout), Gi(Ho, Ho, 0, Cout), Bn * Ho * Ho, Cout, Cin, 9, relu=True,
+                          conv_rounding=True, pe=torch.zeros((Ho * Ho, Cout), device=dev), y_pe=t2.view(torch.float16).reshape(Bn, Ho * Ho, Cout))
+            torch.cuda.synchronize()
+            assert intact(a1, nb2) and intact(a2, nb2), "tokens"
+    for Bn in (37, 5):
+        qkv = (torch.randn((Bn, 400, 1536), generator=g) * 0.3).half().to(dev)
+        nb = Bn * 400 * 512 * 2
+        a, ov = arena(nb)
+        st = _lib.lib().fp_attention_f16_fwd(C.c_void_p(qkv.data_ptr()), C.c_void_p(ov.data_ptr()), Bn, 400, 4, 128, 0,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert st == 0 and intact(a, nb), ("attention", Bn)
+    # patch-embed conv into the padded NHWC buffer
+    for Bn in (5, 3):
+        x = (torch.rand((Bn, 6, 160, 160), generator=g) - 0.5).half().to(dev)
+        w = (torch.randn((64, 294), generator=g) * 0.05).half().to(dev)
+        nb = Bn * 82 * 82 * 64 * 2
+        a, yv = arena(nb)
+        ops.conv7x7s2_bn_relu(x, w, torch.zeros(64, device=dev), torch.ones(64, device=dev), torch.zeros(64, device=dev),
+                              yv.view(torch.float16).reshape(Bn, 82, 82, 64), 1)
+        torch.cuda.synchronize()
+        assert intact(a, nb), ("conv1", Bn)
