@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--mode", default="object", choices=["object", "hypothesis"])
     ap.add_argument("--streams", type=int, default=2, help="hypothesis sub-batches run on concurrent HIP streams (1: none)")
+    ap.add_argument("--serialize", action="store_true", help="issue the sub-batches on ONE stream in the timed region too "
+                    "(the launches of the per-kernel table; used for the rocprofv3 profile that table is checked against)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (instrumented) pass")
     args = ap.parse_args()
@@ -161,6 +163,9 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     use_dist = world > 1 or os.environ.get("FP_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL on one GPU
+    if args.streams > 1:
+        from foundationpose_amd.overlap import reserve_streams
+        reserve_streams(dev, args.streams - 1)      # before RCCL creates its streams (overlap.reserve_streams)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -204,6 +209,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.serialize:
+        refiner.sub.serial = scorer.sub.serial = True
     _log("warmup")
     for _ in range(args.warmup):
         step()
@@ -231,7 +238,7 @@ def main():
             for _ in range(args.steps):
                 step()
         sync()
-        refiner.sub.serial = scorer.sub.serial = False
+        refiner.sub.serial = scorer.sub.serial = args.serialize
 
     total_hyps = N if hyp_mode else world * N
     if rank == 0:
@@ -250,6 +257,7 @@ def main():
                                        f"[feature|pose] per step" if hyp_mode else
                                        f"object-parallel x{world}, one RCCL all-gather of [score|pose] records per step")},
             "concurrency": {"sub_batches": len(refiner.sub.parts(N)), "rows": [e - a for a, e in refiner.sub.parts(N)],
+                            "serialized": bool(args.serialize),
                             "note": "independent hypothesis sub-batches of the step run on concurrent HIP streams in the timed "
                                     "region (foundationpose_amd/overlap.py); the per-kernel table and `roofline` time the same "
                                     "launches issued on one stream"},

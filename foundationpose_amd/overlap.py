@@ -15,12 +15,34 @@ scratch by stream (ops._workspace) or passed per part by the caller.
 import torch
 
 
+# side streams are shared by every predictor of the process (one list per device): ROCm maps HIP streams onto a handful
+# of hardware queues, and streams that share a queue serialise -- with one side stream each for the refiner and the scorer
+# plus RCCL's stream, the RCCL bench ran SLOWER than one stream (46 ms against 41 ms per step)
+_SIDE = {}
+
+
+def reserve_streams(device, k=1):
+    """create -- and use once -- the k shared side streams of `device` now.  ROCm maps the streams of a process onto a few
+    hardware queues (4 by default), binding a stream at its first use; streams that share a queue serialise.  A process
+    that also initialises RCCL (which brings streams of its own) should call this BEFORE
+    torch.distributed.init_process_group: measured on one MI355X with RCCL initialised, 37.7 ms per bench step with the
+    side stream bound first, 43.5-45.9 ms when it was bound afterwards (slower than one stream: 41.0 ms)"""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    side = _SIDE.setdefault(idx, [])
+    while len(side) < k:
+        st = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(st):                  # first use: the runtime binds a stream to its hardware queue lazily
+            torch.zeros(1, device=device)
+        side.append(st)
+    return side[:k]
+
+
 class SubBatches:
     def __init__(self, n_streams=2, min_rows=32):
         self.n_streams = max(1, int(n_streams))
         self.min_rows = int(min_rows)
         self.serial = False      # True: the same parts, all issued on the current stream (isolated per-kernel timing)
-        self._side = {}
 
     def parts(self, N):
         """[(first, last+1)] row ranges: up to n_streams near-equal contiguous parts of at least `min_rows` rows"""
@@ -43,10 +65,7 @@ class SubBatches:
         if self.serial:
             return [torch.cuda.current_stream(device)] * k
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        side = self._side.setdefault(idx, [])
-        while len(side) < k - 1:
-            side.append(torch.cuda.Stream(device=device))
-        return [torch.cuda.current_stream(device)] + side[: k - 1]
+        return [torch.cuda.current_stream(device)] + reserve_streams(device, k - 1)
 
     @staticmethod
     def fork(streams):
