@@ -246,9 +246,16 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
 #endif
   const bool sw = sel == 0 && fp_conv3x3_sw_applicable(p);
   if (sel >= 100) sel = 0;
-  // measured at the bench shapes (scripts/bench_igemm.py): the 256x256 ping-pong kernel wins where both M and N are
-  // large (QKV projection), 128x128 (two workgroups per CU) elsewhere
-  if (!sw && sel == 0) sel = ((p.N % 256) == 0 && (p.M >= 150000 || p.N >= 1024)) ? 7 : 1;
+  // measured at the bench shapes, full batch (M = 252 x 400) and sub-batch (126 x 400), scripts/bench_igemm.py with
+  // FP_N=252|126 and FP_IGEMM_TILE forced (profiles/r02_g_igemm_tiles.log): the 256x256 ping-pong kernel wins for wide
+  // outputs (QKV projection, 0.74 against 0.72 PF/s), for the stride-2 conv with a long reduction (256->512: 0.92-0.98
+  // against 0.89-0.90) and for the 512-wide Linear layers below ~75 k rows (0.63 against 0.58; above, two 128x128
+  // workgroups per CU win 0.67 against 0.62); 128x128 elsewhere (64->128 stride 2: 0.54 against 0.47)
+  if (!sw && sel == 0) {
+    const bool wide = (p.N % 256) == 0;
+    const bool pp = wide && (p.M >= 150000 || p.N >= 1024 || (p.taps == 9 && p.Cin >= 256) || (p.taps == 1 && p.M < 75000 && p.M >= 4096));
+    sel = pp ? 7 : 1;
+  }
   if (sel == 3 && (p.N % 256) != 0) sel = 2;
   if (sel == 7 && (p.N % 256) != 0) sel = 9;
   if (sw) return fp_conv3x3_sw_launch(p, stream);
