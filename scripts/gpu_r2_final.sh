@@ -11,6 +11,8 @@ echo "== bench"; timeout 600 python bench.py > gpurun_out/${T}_bench.json 2> gpu
 echo "== bench --streams 1"; timeout 300 python bench.py --streams 1 --no-cpu-baseline > gpurun_out/${T}_bench_streams1.json 2> /dev/null; cut -c100-260 gpurun_out/${T}_bench_streams1.json
 echo "== rocprof kernel stats (bench, default = 2 sub-batch streams)"; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_prof -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_prof.log 2>&1
 head -12 gpurun_out/${T}_prof/bench_kernel_stats.csv | cut -c1-170
+echo "== rocprof kernel stats (bench --serialize: the sub-batch launches on one stream throughout)"; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_profs -o bench -- python bench.py --serialize --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_bench_serialize.json 2> gpurun_out/${T}_profs.log
+head -6 gpurun_out/${T}_profs/bench_kernel_stats.csv | cut -c1-170
 echo "== rocprof kernel stats (bench --streams 1)"; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_prof1 -o bench -- python bench.py --streams 1 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-table > gpurun_out/${T}_prof1.log 2>&1
 head -8 gpurun_out/${T}_prof1/bench_kernel_stats.csv | cut -c1-170
 echo "== per-layer igemm"; timeout 200 python scripts/bench_igemm.py > gpurun_out/${T}_igemm_layers.log 2>&1; grep -c TFLOPs gpurun_out/${T}_igemm_layers.log
