@@ -23,6 +23,18 @@
 #include "igemm_common.h"
 #include "igemm_epilogue.h"
 
+#ifdef FP_PROFILE_BUILD
+// profiling build only: 100 MHz wall-clock time per phase, summed over the workgroups of a launch (scripts/dbg_conv_sw.py)
+__device__ unsigned long long sw_dbg[8];
+extern "C" int fp_dbg_conv_sw(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, ~0ull, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sw_dbg), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_dbg), 8 * sizeof(unsigned long long));
+}
+#define SW_CLK(t) const unsigned long long t = wall_clock64()
+#else
+#define SW_CLK(t)
+#endif
+
 namespace {
 
 constexpr int SW_BK = 32, SW_NSTW = 4;
@@ -63,6 +75,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
   constexpr int LDS_MAIN = ig_lds_main<BM, BN>(STAGES_BYTES);
   auto swz = [](int row) { return (row >> 2) & 3; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SW_CLK(t_start);
   unsigned char* const patch = smem;                              // 2 x SW_PATCH_BYTES
   unsigned char* const wring = smem + 2 * SW_PATCH_BYTES;         // SW_NSTW x W_BYTES
   const int tid = threadIdx.x, lane = tid & 63;
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
   stage_w(0, 2, 2);
   sw_wait_vm<2 * WI>();
   __builtin_amdgcn_s_barrier();
+  SW_CLK(t_cold);
   if (grp) __builtin_amdgcn_s_barrier();           // group 1 sits out interval 0
 
   half8 fa[2][TM], fw[2][2];
@@ -228,7 +242,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
   chunk(ncc - 1, std::true_type{});
   if (!grp) __builtin_amdgcn_s_barrier();          // group 0 waits out group 1's last compute cluster
   __syncthreads();
+  SW_CLK(t_loop);
   ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
+#ifdef FP_PROFILE_BUILD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores drained: the workgroup's resources are free from here
+  SW_CLK(t_end);
+  if (tid == 0) {
+    atomicAdd(&sw_dbg[0], t_cold - t_start); atomicAdd(&sw_dbg[1], t_loop - t_cold); atomicAdd(&sw_dbg[2], t_end - t_loop);
+    atomicAdd(&sw_dbg[3], 1ull); atomicMin(&sw_dbg[6], t_start); atomicMax(&sw_dbg[7], t_end);
+  }
+#endif
 }
 
 template <int BM, int BN, int TM>
