@@ -242,7 +242,7 @@ def main():
     # third pass, only when the step is split: the same kernels in ONE launch sequence over all hypotheses -- the launch
     # sizes of `--streams 1` and of rounds 1 / 2a, for a like-for-like per-launch figure of the dominant kernel
     timers_full = ops.KernelTimers()
-    if not args.no_kernel_table and len(refiner.sub.parts(N)) > 1:
+    if not args.no_kernel_table and len(refiner.sub.parts(N, dev)) > 1:
         ns = refiner.sub.n_streams
         refiner.sub.n_streams = scorer.sub.n_streams = 1
         step()
@@ -268,7 +268,7 @@ def main():
                        "parallelism": (f"hypothesis-parallel x{world}: {N} hypotheses of one object sharded, one RCCL all-gather of "
                                        f"[feature|pose] per step" if hyp_mode else
                                        f"object-parallel x{world}, one RCCL all-gather of [score|pose] records per step")},
-            "concurrency": {"sub_batches": len(refiner.sub.parts(N)), "rows": [e - a for a, e in refiner.sub.parts(N)],
+            "concurrency": {"sub_batches": len(refiner.sub.parts(N, dev)), "rows": [e - a for a, e in refiner.sub.parts(N, dev)],
                             "serialized": bool(args.serialize),
                             "note": "independent hypothesis sub-batches of the step run on concurrent HIP streams in the timed "
                                     "region (foundationpose_amd/overlap.py); the per-kernel table and `roofline` time the same "

@@ -39,7 +39,7 @@ class GraphedTracker:
         # the tracker: the outputs and one rasteriser scratch per part here, the encoder's activation sets by
         # (batch, H, W, slot) in the plan (never dropped)
         oh, ow = int(refiner.cfg["input_resize"][0]), int(refiner.cfg["input_resize"][1])
-        self.parts = refiner.sub.parts(self.N)
+        self.parts = refiner.sub.parts(self.N, self.dev)
         self.workspace = [torch.empty(max(16, ops.workspace_bytes(b - a, self.handle.V, self.handle.T, oh, ow)),
                                       dtype=torch.uint8, device=self.dev) for a, b in self.parts]
         self.outs = refiner.alloc_outputs(self.N, self.dev) + (self.R,)

@@ -35,7 +35,43 @@ def reserve_streams(device, k=1):
         with torch.cuda.stream(st):                  # first use: the runtime binds a stream to its hardware queue lazily
             torch.zeros(1, device=device)
         side.append(st)
+        _OVERLAPS[(idx, len(side) - 1)] = _overlaps_with_current(st, device)
     return side[:k]
+
+
+_OVERLAPS = {}
+
+
+def _overlaps_with_current(st, device, cycles=400_000):
+    """does work on `st` run beside work on the current stream?  Two spin kernels, one per stream, against one alone
+    (about 1 ms, once per side stream).  A stream that landed on the main stream's hardware queue serialises with it."""
+    if torch.cuda.is_current_stream_capturing():
+        return True                                  # cannot measure inside a capture; the eager warm-up has done it
+    main = torch.cuda.current_stream(device)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda._sleep(cycles)                        # warm the spin kernel
+    torch.cuda.synchronize(device)
+    e[0].record(main)
+    torch.cuda._sleep(cycles)
+    e[1].record(main)
+    st.wait_stream(main)
+    e[2].record(main)
+    with torch.cuda.stream(st):
+        torch.cuda._sleep(cycles)
+    torch.cuda._sleep(cycles)
+    main.wait_stream(st)
+    e[3].record(main)
+    torch.cuda.synchronize(device)
+    alone, pair = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
+    return pair < 1.5 * alone
+
+
+def side_streams_overlap(device, k=1):
+    """True if the first k side streams of `device` were measured to run beside the main stream"""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    reserve_streams(device, k)
+    return all(_OVERLAPS.get((idx, i), True) for i in range(k))
 
 
 class SubBatches:
@@ -44,9 +80,14 @@ class SubBatches:
         self.min_rows = int(min_rows)
         self.serial = False      # True: the same parts, all issued on the current stream (isolated per-kernel timing)
 
-    def parts(self, N):
-        """[(first, last+1)] row ranges: up to n_streams near-equal contiguous parts of at least `min_rows` rows"""
+    def parts(self, N, device=None):
+        """[(first, last+1)] row ranges: up to n_streams near-equal contiguous parts of at least `min_rows` rows.  With a
+        CUDA `device` given, one part if its side streams do not overlap with the main stream (sub-batches issued one
+        after the other are slower than one launch sequence over the whole batch)"""
         k = min(self.n_streams, max(1, N // max(1, self.min_rows)))
+        if k > 1 and device is not None and torch.device(device).type == "cuda" and not self.serial \
+                and not side_streams_overlap(device, k - 1):
+            k = 1
         if k <= 1:
             return [(0, N)]
         base, extra = divmod(N, k)

@@ -180,7 +180,7 @@ class PoseRefinePredictor:
         self.plan()
         N = poses.shape[0]
         dev = poses.device
-        parts = self.sub.parts(N)
+        parts = self.sub.parts(N, dev)
         if workspace is not None and torch.is_tensor(workspace):
             workspace = [workspace]
         if workspace is not None and len(workspace) != len(parts):

@@ -98,7 +98,7 @@ class ScorePredictor:
         oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
         # the encoder + per-hypothesis attention see one hypothesis at a time: sub-batches on concurrent streams
         # (overlap.py), joined before the cross-hypothesis attention, which needs all N feature rows
-        parts = self.sub.parts(N)
+        parts = self.sub.parts(N, dev)
         feats = torch.empty((N, 512), dtype=plan.dtype, device=dev)
         streams = self.sub.streams(dev, len(parts))
         self.sub.fork(streams)

@@ -420,6 +420,9 @@ def test_sub_batches_on_concurrent_streams_change_nothing(scene, dev, gmesh, fra
         refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev, n_streams=ns)
         scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), device=dev, n_streams=ns)
         assert len(refiner.sub.parts(len(P))) == min(ns, 2) and len(refiner.sub.parts(63)) == 1
+        from foundationpose_amd.overlap import side_streams_overlap
+        assert side_streams_overlap(dev, 1), "the sub-batch stream does not run beside the main stream on this box"
+        assert len(refiner.sub.parts(len(P), dev)) == min(ns, 2)
         p, _ = refiner.predict(rgb, depth, scene["K"], P, xyz, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=3)
         s, _ = scorer.predict(rgb, depth, scene["K"], p, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
         res[ns] = (p.clone(), s.clone(), refiner.last_trans_update.clone(), refiner.last_rot_update.clone(),
