@@ -3,6 +3,8 @@ libfp_amd.so (device ops) and numpy (init-time setup).  Citations are to /root/r
 import logging
 import random
 
+import math
+
 import numpy as np
 import torch
 
@@ -214,44 +216,45 @@ def projection_matrix_from_intrinsics(K, height, width, znear, zfar, window_coor
 
 # ------------------------------------------------------------------ hypothesis-generation setup (CPU, init time)
 def euler_matrix(ai, aj, ak, axes="sxyz"):
-    """Static-xyz Euler angles -> 4x4 (what transformations.euler_matrix returns for the default axes)."""
+    """Static-xyz Euler angles -> 4x4, entry by entry as transformations.euler_matrix (Gohlke's transformations.py [3P],
+    imported by the reference's Utils.py:34) computes it for its default axes: R = Rz(ak) Ry(aj) Rx(ai) written out in
+    products of the six sines / cosines (so that e.g. a 90 degree step carries the same 6e-17 residues)."""
     if axes != "sxyz":
         raise NotImplementedError
-    ci, si, cj, sj, ck, sk = np.cos(ai), np.sin(ai), np.cos(aj), np.sin(aj), np.cos(ak), np.sin(ak)
-    Rx = np.array([[1, 0, 0], [0, ci, -si], [0, si, ci]])
-    Ry = np.array([[cj, 0, sj], [0, 1, 0], [-sj, 0, cj]])
-    Rz = np.array([[ck, -sk, 0], [sk, ck, 0], [0, 0, 1]])
+    si, sj, sk = math.sin(ai), math.sin(aj), math.sin(ak)
+    ci, cj, ck = math.cos(ai), math.cos(aj), math.cos(ak)
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
     M = np.eye(4)
-    M[:3, :3] = Rz @ Ry @ Rx
+    M[0, 0], M[0, 1], M[0, 2] = cj * ck, sj * sc - cs, sj * cc + ss
+    M[1, 0], M[1, 1], M[1, 2] = cj * sk, sj * ss + cc, sj * cs - sc
+    M[2, 0], M[2, 1], M[2, 2] = -sj, cj * si, cj * ci
     return M
 
 
-def icosphere_vertices(subdivisions=1):
-    """Unit icosphere vertices (12 icosahedron vertices, then edge midpoints per subdivision level).
-    Vertex ORDER differs from trimesh.creation.icosphere; it only permutes the hypothesis order."""
+def icosphere_vertices(subdivisions=1, radius=1.0):
+    """Vertices of trimesh.creation.icosphere(subdivisions, radius) [3P: trimesh 4.2.2 is not installed here; restated from
+    its published algorithm -- creation.icosahedron / remesh.subdivide / the spherical re-projection -- so that the ORDER
+    of the views, hence of the 252 hypotheses (estimater.py:106-124) and of what the greedy cluster_poses keeps for a
+    symmetric object, is the reference's]:
+      * the 12 icosahedron vertices (+-1, +-t, 0) cyclic, divided by sqrt(2 + t);
+      * per level: one midpoint per unique edge, appended in the order of trimesh's row hash of the sorted edge (lo, hi) --
+        lo | hi << 32, i.e. by hi, then lo; then every vertex is moved to the sphere by v += v/|v| * (radius - |v|)."""
     t = (1.0 + 5.0 ** 0.5) / 2.0
-    v = [[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
-         [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]]
-    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
-         [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
-         [8, 6, 7], [9, 8, 1]]
-    v = [np.asarray(p, dtype=float) / np.linalg.norm(p) for p in v]
+    v = np.array([-1, t, 0, 1, t, 0, -1, -t, 0, 1, -t, 0, 0, -1, t, 0, 1, t, 0, -1, -t, 0, 1, -t, t, 0, -1, t, 0, 1, -t, 0, -1,
+                  -t, 0, 1], dtype=np.float64).reshape(-1, 3) / np.sqrt(2.0 + t)
+    f = np.array([0, 11, 5, 0, 5, 1, 0, 1, 7, 0, 7, 10, 0, 10, 11, 1, 5, 9, 5, 11, 4, 11, 10, 2, 10, 7, 6, 7, 1, 8, 3, 9, 4, 3, 4,
+                  2, 3, 2, 6, 3, 6, 8, 3, 8, 9, 4, 9, 5, 2, 4, 11, 6, 2, 10, 8, 6, 7, 9, 8, 1], dtype=np.int64).reshape(-1, 3)
     for _ in range(subdivisions):
-        cache, nf = {}, []
-
-        def mid(a, b):
-            key = (min(a, b), max(a, b))
-            if key not in cache:
-                m = (v[a] + v[b]) / 2.0
-                v.append(m / np.linalg.norm(m))
-                cache[key] = len(v) - 1
-            return cache[key]
-
-        for a, b, c in f:
-            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
-            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
-        f = nf
-    return np.asarray(v)
+        edges = np.sort(f[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2), axis=1)
+        _, first, inverse = np.unique(edges[:, 0] | (edges[:, 1] << 32), return_index=True, return_inverse=True)
+        mid = v[edges[first]].mean(axis=1)
+        m = inverse.reshape(-1, 3) + len(v)
+        f = np.column_stack([f[:, 0], m[:, 0], m[:, 2], m[:, 0], f[:, 1], m[:, 1], m[:, 2], m[:, 1], f[:, 2], m[:, 0], m[:, 1],
+                             m[:, 2]]).reshape(-1, 3)
+        v = np.vstack((v, mid))
+        scalar = np.sqrt(np.dot(v ** 2, [1, 1, 1]))
+        v = v + (v / scalar.reshape(-1, 1)) * (radius - scalar).reshape(-1, 1)
+    return v
 
 
 def sample_views_icosphere(n_views, subdivisions=None, radius=1):
@@ -259,9 +262,9 @@ def sample_views_icosphere(n_views, subdivisions=None, radius=1):
     points from the vertex to the centre, x = world-up (0,0,1) x z (or (1,0,0) at the poles), y = z x x."""
     if subdivisions is None:
         subdivisions = 1
-        while icosphere_vertices(subdivisions).shape[0] < n_views:
+        while icosphere_vertices(subdivisions, radius).shape[0] < n_views:
             subdivisions += 1
-    eye = icosphere_vertices(subdivisions) * radius
+    eye = icosphere_vertices(subdivisions, radius)
     fwd = -eye / np.linalg.norm(eye, axis=1, keepdims=True)
     right = np.cross(np.array([[0.0, 0.0, 1.0]]), fwd)
     right[~right.any(axis=1)] = (1.0, 0.0, 0.0)        # looking along the up axis: any perpendicular will do, the reference picks +x
@@ -299,14 +302,14 @@ def symmetry_tfs_from_info(info, rot_angle_discrete=5):
     if discrete is not None:
         for m in np.asarray(discrete, dtype=float).reshape(-1, 4, 4):
             m = m.copy()
-            m[:3, 3] /= 1000.0
+            m[:3, 3] *= 0.001
             out.append(m)
     continuous = info.get("symmetries_continuous")
     if continuous:
         sym = continuous[0]
         axis = np.asarray(sym["axis"], dtype=float).reshape(3)
         positive = [i for i in range(3) if axis[i] > 0]
-        angles = np.deg2rad(np.arange(0, 360, rot_angle_discrete))
+        angles = np.arange(0, 360, rot_angle_discrete) / 180.0 * np.pi        # Utils.py:820-824
         for ang in (angles if positive else [0.0]):
             euler = [0.0, 0.0, 0.0]
             if positive:

@@ -104,7 +104,12 @@ __device__ __forceinline__ VtxRec project_vertex(const HypConst& h, float vx, fl
 
 __device__ __forceinline__ int vx_of(uint32_t xy) { return (int)(int16_t)(xy & 0xFFFFu); }
 __device__ __forceinline__ int vy_of(uint32_t xy) { return (int)(int16_t)(xy >> 16); }
-__device__ __forceinline__ bool edge_owner(int dx, int dy) { return (dy > 0) || (dy == 0 && dx < 0); }
+/* tie rule for a pixel centre exactly on an edge (vertices oriented to positive area in THIS, y-down, crop space): the
+ * top-left rule of a rasteriser working in nvdiffrast's y-up window space -- the reference flips the rows AFTER
+ * rasterising (Utils.py:216-218) -- seen from here: an edge owns its points if it runs downwards in window space
+ * (dy > 0 in both spaces, because the orientation fix reverses the edge when the rows are flipped), and a horizontal
+ * edge if it runs towards -x there = towards +x here. */
+__device__ __forceinline__ bool edge_owner(int dx, int dy) { return (dy > 0) || (dy == 0 && dx > 0); }
 
 struct TriSetup {
   int x0, y0, x1, y1, x2, y2;

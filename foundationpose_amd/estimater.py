@@ -139,8 +139,8 @@ class FoundationPose:
         v0, v1, u0, u1 = stats.tolist()                            # six scalars cross PCIe, not a 640x480 image
         lo, hi = mid.tolist()
         zc = float(np.float32(np.float32(lo) + np.float32(hi)) / np.float32(2.0)) if lo != hi else lo
-        ray = np.linalg.solve(np.asarray(K, dtype=np.float64), np.array([(u0 + u1) / 2.0, (v0 + v1) / 2.0, 1.0]))
-        return ray * zc
+        center = (np.linalg.inv(K) @ np.asarray([(u0 + u1) / 2.0, (v0 + v1) / 2.0, 1]).reshape(3, 1)) * zc   # estimater.py:149
+        return center.reshape(3)
 
     # ------------------------------------------------------------------ estimater.py:159-240
     def register(self, K, rgb, depth, ob_mask, ob_id=None, glctx=None, iteration=5):

@@ -215,7 +215,12 @@ typedef struct {
   int valid;
 } fpo_vtx;
 
-static inline int edge_owner(int dx, int dy) { return (dy > 0) || (dy == 0 && dx < 0); }
+/* tie rule for a pixel centre exactly on an edge (vertices oriented to positive area in THIS, y-down, crop space): the
+ * top-left rule of a rasteriser working in nvdiffrast's y-up window space -- the reference flips the rows AFTER
+ * rasterising (Utils.py:216-218) -- seen from here: an edge owns its points if it runs downwards in window space
+ * (dy > 0 in both spaces, because the orientation fix reverses the edge when the rows are flipped), and a horizontal
+ * edge if it runs towards -x there = towards +x here. */
+static inline int edge_owner(int dx, int dy) { return (dy > 0) || (dy == 0 && dx > 0); }
 
 typedef struct {
   int a0, a1, a2;       /* vertex slots after orientation fix (0..2 into the face) */

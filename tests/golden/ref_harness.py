@@ -14,6 +14,10 @@ published semantics -- these are the only "unpinned" pieces l
   nvdiffrast.torch  : rasterize / interpolate / texture           (App. B.1)
   kornia            : geometry.transform.warp_perspective          (App. B.2, on top of torch's F.grid_sample)
   pytorch3d         : so3_exp_map, rotation_6d_to_matrix           (App. B.3)
+  trimesh           : creation.icosphere (vertices only)           (App. B.5; trimesh 4.2.2 creation.icosahedron + remesh.subdivide)
+  transformations   : euler_matrix (static xyz), Gohlke's formula restated, cross-checked against scipy's Rotation
+  mycpp             : cluster_poses -- float32 numpy restatement of mycpp/src/app/pybind_api.cpp:24-68 + Utils.cpp:21-26
+                      (Eigen / Boost are not in this image, so the C++ cannot be compiled)
 Every other missing import (trimesh, open3d, cv2, warp, omegaconf, ...) is a MagicMock: imported, never called on
 this path.  'cuda' device requests are redirected to the CPU.
 """
@@ -210,6 +214,99 @@ def _rotation_6d_to_matrix(d6):
     return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
 
 
+# ----------------------------------------------------------------------------------------------- trimesh stand-in
+def _icosphere(subdivisions=3, radius=1.0, **kw):
+    """trimesh.creation.icosphere [3P]: icosahedron() scaled to the unit sphere, then per level remesh.subdivide (one
+    midpoint per unique edge; new vertices appended in the order of grouping.unique_rows' integer row hash of the sorted
+    edge, low index in the low 32 bits) followed by the re-projection v += v/|v| * (radius - |v|).  Written with dicts
+    and explicit sorting, independently of foundationpose_amd.Utils.icosphere_vertices."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    verts = [np.array(p, dtype=np.float64) / np.sqrt(2.0 + t) for p in
+             ([-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1],
+              [t, 0, 1], [-t, 0, -1], [-t, 0, 1])]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+             (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(int(subdivisions)):
+        edges = set()
+        for a, b, c in faces:
+            for e in ((a, b), (b, c), (c, a)):
+                edges.add((min(e), max(e)))
+        order = sorted(edges, key=lambda e: (e[1], e[0]))           # hash = lo | hi << 32
+        index = {e: len(verts) + i for i, e in enumerate(order)}
+        new = [(verts[lo] + verts[hi]) / 2.0 for lo, hi in order]
+        nf = []
+        for a, b, c in faces:
+            ab, bc, ca = index[(min(a, b), max(a, b))], index[(min(b, c), max(b, c))], index[(min(c, a), max(c, a))]
+            nf += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+        faces = nf
+        verts = verts + new
+        out = []
+        for p in verts:
+            scalar = np.sqrt(p[0] ** 2 + p[1] ** 2 + p[2] ** 2)
+            out.append(p + (p / scalar) * (radius - scalar))
+        verts = out
+    return types.SimpleNamespace(vertices=np.array(verts), faces=np.array(faces))
+
+
+def _make_transformations():
+    """transformations.euler_matrix for the default axes 'sxyz' [3P: Gohlke's transformations.py, restated]: with
+    i,j,k = 0,1,2 and no parity / repetition / frame flip it fills M[i,i]=cj*ck, M[i,j]=sj*sc-cs, M[i,k]=sj*cc+ss,
+    M[j,i]=cj*sk, M[j,j]=sj*ss+cc, M[j,k]=sj*cs-sc, M[k,i]=-sj, M[k,j]=cj*si, M[k,k]=cj*ci (cc=ci*ck, cs=ci*sk, sc=si*ck,
+    ss=si*sk).  Cross-checked against scipy.spatial.transform.Rotation (extrinsic xyz) at import."""
+    from scipy.spatial.transform import Rotation
+    m = types.ModuleType("transformations")
+
+    def euler_matrix(ai, aj, ak, axes="sxyz"):
+        assert axes == "sxyz"
+        si, sj, sk = math.sin(ai), math.sin(aj), math.sin(ak)
+        ci, cj, ck = math.cos(ai), math.cos(aj), math.cos(ak)
+        cc, cs = ci * ck, ci * sk
+        sc, ss = si * ck, si * sk
+        M = np.identity(4)
+        M[0, 0] = cj * ck
+        M[0, 1] = sj * sc - cs
+        M[0, 2] = sj * cc + ss
+        M[1, 0] = cj * sk
+        M[1, 1] = sj * ss + cc
+        M[1, 2] = sj * cs - sc
+        M[2, 0] = -sj
+        M[2, 1] = cj * si
+        M[2, 2] = cj * ci
+        return M
+    for ang in ((0.3, -1.1, 2.5), (0, 0, math.pi / 2), (math.pi, 0.2, 0)):
+        assert np.abs(euler_matrix(*ang)[:3, :3] - Rotation.from_euler("xyz", ang).as_matrix()).max() < 1e-15
+    m.euler_matrix = euler_matrix
+    m.__all__ = ["euler_matrix"]
+    return m
+
+
+def _cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
+    """mycpp.cluster_poses (pybind_api.cpp:24-68) in float32 numpy: greedy, first pose always kept, a pose joins the first
+    cluster within dist_diff whose rotation is within angle_diff (degrees) of pose @ tf for some symmetry tf;
+    rotationGeodesicDistance = acos(clamp((trace(R1 R2^T) - 1) / 2)) (mycpp/src/Utils.cpp:21-26)."""
+    P = np.asarray(poses_in, dtype=np.float32)
+    S = np.asarray(symmetry_tfs, dtype=np.float32)
+    thres = np.float32(np.float32(angle_diff) / 180.0 * math.pi)
+    out = [P[0]]
+    for i in range(1, len(P)):
+        cur, isnew = P[i], True
+        for cl in out:
+            if np.linalg.norm(cl[:3, 3] - cur[:3, 3]) >= dist_diff:
+                continue
+            for tf in S:
+                R1 = (cur @ tf)[:3, :3]
+                cs = np.float32((np.trace(R1 @ cl[:3, :3].T) - np.float32(1)) / np.float32(2.0))
+                cs = max(min(cs, np.float32(1)), np.float32(-1))
+                if np.arccos(cs) < thres:
+                    isnew = False
+                    break
+            if not isnew:
+                break
+        if isnew:
+            out.append(cur)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- torch 'cuda' -> cpu
 def _cpu_device_patch():
     def fix(fn):
@@ -244,10 +341,10 @@ def load_reference():
     if _loaded is not None:
         return _loaded
     _cpu_device_patch()
-    mocks = ["trimesh", "imageio", "joblib", "open3d", "cv2", "ruamel", "ruamel.yaml", "transformations", "torchvision",
+    mocks = ["imageio", "joblib", "open3d", "cv2", "ruamel", "ruamel.yaml", "torchvision",
              "h5py", "warp", "omegaconf", "pytorch3d.renderer", "pytorch3d.renderer.mesh", "pytorch3d.structures",
              "pytorch3d.renderer.mesh.rasterize_meshes", "pytorch3d.renderer.mesh.shader", "pytorch3d.renderer.mesh.textures",
-             "mycpp", "mycpp.build", "mycpp.build.mycpp", "bundlesdf", "bundlesdf.mycuda", "kaolin", "sklearn",
+             "bundlesdf", "bundlesdf.mycuda", "kaolin", "sklearn",
              "sklearn.metrics", "matplotlib", "matplotlib.pyplot", "pandas", "psutil", "yaml"]
     for m in mocks:
         if m not in sys.modules or m in ("yaml",):
@@ -258,6 +355,17 @@ def load_reference():
             except Exception:
                 pass
             sys.modules[m] = mock.MagicMock(name=m)
+    tm = mock.MagicMock(name="trimesh")
+    tm.creation.icosphere = _icosphere
+    sys.modules["trimesh"] = tm
+    sys.modules["transformations"] = _make_transformations()
+    mc = types.ModuleType("mycpp.build.mycpp")
+    mc.cluster_poses = _cluster_poses
+    mcb = types.ModuleType("mycpp.build")
+    mcb.mycpp = mc
+    mcp = types.ModuleType("mycpp")
+    mcp.build = mcb
+    sys.modules["mycpp"], sys.modules["mycpp.build"], sys.modules["mycpp.build.mycpp"] = mcp, mcb, mc
     p3d = types.ModuleType("pytorch3d")
     p3dt = types.ModuleType("pytorch3d.transforms")
     for n in ("so3_log_map", "se3_exp_map", "se3_log_map", "matrix_to_axis_angle", "matrix_to_euler_angles", "euler_angles_to_matrix"):
@@ -280,5 +388,6 @@ def load_reference():
     ns.score = importlib.import_module("learning.training.predict_score")
     ns.refine_network = importlib.import_module("learning.models.refine_network")
     ns.score_network = importlib.import_module("learning.models.score_network")
+    ns.estimater = importlib.import_module("estimater")
     _loaded = ns
     return ns
