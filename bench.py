@@ -133,6 +133,63 @@ def _respawn(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+class ClockSampler:
+    """samples the GPU's shader clock (and socket power) from the amdgpu hwmon files while the timed region runs, so that a
+    box-to-box difference of the step time can be attributed (the chip clocks to its power budget: MI355X_MICROARCH.md,
+    "DVFS give-back").  Nothing here touches the GPU; a missing file gives nulls."""
+
+    def __init__(self, index=0, period_s=0.005):
+        import glob
+        import threading
+        self.freq = self.power = None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        if cards:
+            self.freq = cards[min(index, len(cards) - 1)]
+            pw = os.path.join(os.path.dirname(self.freq), "power1_average")
+            self.power = pw if os.path.exists(pw) else None
+        self.period, self.f, self.p = period_s, [], []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read(self.freq) if self.freq else None
+            if v is not None:
+                self.f.append(v / 1e6)
+            w = self._read(self.power) if self.power else None
+            if w is not None:
+                self.p.append(w / 1e6)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.freq:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.freq:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.f:
+            return {"sclk_MHz_mean": None, "samples": 0, "source": self.freq}
+        import statistics
+        out = {"sclk_MHz_mean": statistics.fmean(self.f), "sclk_MHz_min": min(self.f), "sclk_MHz_max": max(self.f),
+               "samples": len(self.f), "source": self.freq}
+        if self.p:
+            out["power_W_mean"] = statistics.fmean(self.p)
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +197,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--hyps", type=int, default=252)
     ap.add_argument("--refine-iters", type=int, default=5)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "torch_amp"],
+                    help="fp16: the deployed plan, every network op on libfp_amd.so; torch_amp: the nn.Module under torch.autocast on "
+                         "PyTorch-ROCm (MIOpen / rocBLAS) behind the same predictors = BASELINE configs[1] literally; fp32: parity config")
     ap.add_argument("--mode", default="object", choices=["object", "hypothesis"])
     ap.add_argument("--streams", type=int, default=2, help="hypothesis sub-batches run on concurrent HIP streams (1: none)")
     ap.add_argument("--serialize", action="store_true", help="issue the sub-batches on ONE stream in the timed region too "
@@ -216,11 +275,13 @@ def main():
         step()
     sync()
     _log("timed region")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec = step()
-    sync()
-    dt = time.perf_counter() - t0
+    clock = ClockSampler(local_rank)
+    with clock:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rec = step()
+        sync()
+        dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,11 +322,14 @@ def main():
             "value": total_hyps * args.steps / dt, "unit": "pose-hypotheses/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if hyp_mode else "weak",
-            "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: synthetic can (V={V}, T={T}), one 640x480 RGB-D frame per rank, "
                                    f"{N} hypotheses, {R} refine iterations + 1 score pass, 160x160 crops, random-init weights",
                        "hypotheses_per_gpu": (N + world - 1) // world if hyp_mode else N, "refine_iterations": R,
-                       "parallelism": (f"hypothesis-parallel x{world}: {N} hypotheses of one object sharded, one RCCL all-gather of "
+                       "network": {"fp16": "libfp_amd.so (hand-written MFMA kernels)", "torch_amp": "PyTorch-ROCm under torch.autocast "
+                                   "(MIOpen / rocBLAS / ATen)", "fp32": "PyTorch-ROCm fp32"}[args.precision],
+                       "parallelism": ("single GPU, no collective (torch.distributed not initialised)" if not use_dist else
+                                       f"hypothesis-parallel x{world}: {N} hypotheses of one object sharded, one RCCL all-gather of "
                                        f"[feature|pose] per step" if hyp_mode else
                                        f"object-parallel x{world}, one RCCL all-gather of [score|pose] records per step")},
             "concurrency": {"sub_batches": len(refiner.sub.parts(N, dev)), "rows": [e - a for a, e in refiner.sub.parts(N, dev)],
@@ -273,6 +337,7 @@ def main():
                             "note": "independent hypothesis sub-batches of the step run on concurrent HIP streams in the timed "
                                     "region (foundationpose_amd/overlap.py); the per-kernel table and `roofline` time the same "
                                     "launches issued on one stream"},
+            "clock": clock.summary(),
             "network_mfma": {"algorithmic_TFLOP_per_step": flops / 1e3, "achieved_TFLOPs": flops / 1e3 / (dt / args.steps),
                              "frac_of_mfma_peak": flops / 1e3 / (dt / args.steps) / (MFMA_PEAK_TFLOPS * world)},
         }

@@ -1,6 +1,7 @@
 // Shared helpers for libfp_amd.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/fp_amd.h"
@@ -41,15 +42,22 @@ struct fp_k9d { double v[9]; };
 static inline int fp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device).
-// Use as FP_SET_MAX_LDS(kernel_symbol, bytes) right before the launch.
-#define FP_SET_MAX_LDS(kernel, bytes)                                                                              \
-  do {                                                                                                             \
-    static unsigned long long done_ = 0ull;                                                                        \
-    int dev_ = 0;                                                                                                  \
-    (void)hipGetDevice(&dev_);                                                                                     \
-    if (!((done_ >> (dev_ & 63)) & 1ull)) {                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (bytes));                                                                          \
-      done_ |= 1ull << (dev_ & 63);                                                                                \
-    }                                                                                                              \
+// Use as FP_SET_MAX_LDS(kernel_symbol, bytes) right before the launch.  Thread-safe (one host thread per device is the
+// multi-GPU use): the per-device "done" bit is published with an atomic OR only AFTER the attribute call has returned, so a
+// racing thread at worst repeats the (idempotent) call; devices >= 64 are not cached.  A failing call is reported.
+#define FP_SET_MAX_LDS(kernel, bytes)                                                                                 \
+  do {                                                                                                                \
+    static std::atomic<unsigned long long> done_{0ull};                                                               \
+    int dev_ = 0;                                                                                                     \
+    (void)hipGetDevice(&dev_);                                                                                        \
+    if (dev_ < 0 || dev_ >= 64 || !((done_.load(std::memory_order_acquire) >> dev_) & 1ull)) {                        \
+      const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                               \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));                 \
+      if (e_ != hipSuccess) {                                                                                         \
+        fp_set_error("hipFuncSetAttribute(%s, %d bytes of LDS) failed on device %d: %s", #kernel, (int)(bytes), dev_, \
+                     hipGetErrorString(e_));                                                                          \
+        return FP_ERR_LAUNCH;                                                                                         \
+      }                                                                                                               \
+      if (dev_ >= 0 && dev_ < 64) done_.fetch_or(1ull << dev_, std::memory_order_release);                            \
+    }                                                                                                                 \
   } while (0)

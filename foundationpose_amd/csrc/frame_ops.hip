@@ -165,7 +165,9 @@ __global__ void k_pose_update(const float* __restrict__ trans, const float* __re
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float v = trans[n * 3 + c];
-      if (!normalize_xyz) v = tanhf(v) * tn.v[c];
+      // 'tracknet' (:195-199) squashes the raw output only when the crops are NOT normalised; any other trans_rep is the
+      // plain `else` (:217-218): the raw output.  With normalize_xyz the two coincide (:232-233).
+      if (!normalize_xyz) v = (trans_rep == FP_TRANS_RAW) ? v : tanhf(v) * tn.v[c];
       else v = v * (mesh_diameter / 2.0f);
       dt[c] = v;
     }

@@ -104,6 +104,16 @@ __device__ __forceinline__ VtxRec project_vertex(const HypConst& h, float vx, fl
 
 __device__ __forceinline__ int vx_of(uint32_t xy) { return (int)(int16_t)(xy & 0xFFFFu); }
 __device__ __forceinline__ int vy_of(uint32_t xy) { return (int)(int16_t)(xy >> 16); }
+// phase-skip bits for scripts/raster_phases.py exist only in libfp_amd_profile.so (-DFP_PROFILE_BUILD); the product
+// kernel has no such branches and fp_render_crops rejects flag bits it does not define
+#ifdef FP_PROFILE_BUILD
+#define FP_PROF_FLAG(flags, bit) (((flags) & (bit)) != 0)
+#define FP_RENDER_FLAG_MASK (FP_FLAG_NORMALIZE_XYZ | FP_FLAG_OUT_F16 | 0xF0000)
+#else
+#define FP_PROF_FLAG(flags, bit) false
+#define FP_RENDER_FLAG_MASK (FP_FLAG_NORMALIZE_XYZ | FP_FLAG_OUT_F16)
+#endif
+
 /* tie rule for a pixel centre exactly on an edge (vertices oriented to positive area in THIS, y-down, crop space): the
  * top-left rule of a rasteriser working in nvdiffrast's y-up window space -- the reference flips the rows AFTER
  * rasterising (Utils.py:216-218) -- seen from here: an edge owns its points if it runs downwards in window space
@@ -293,13 +303,13 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
   // ---- phase 1: the strip's triangle list -> LDS z-buffer.  One lane per triangle; a triangle whose clipped bounding
   // box exceeds FP_BIG_CELLS pixels (the fan triangles of a cap span 50 x 16 of them) would stall its whole wave in
   // the per-lane pixel loop, so it is queued and rasterised afterwards by all lanes together (pixel-parallel).
-  const int cnt = (flags & 0x20000) ? 0 : ws.counts[n * nstrips + strip];   // 0x20000: profiling aid, skip phase 1
+  const int cnt = FP_PROF_FLAG(flags, 0x20000) ? 0 : ws.counts[n * nstrips + strip];   // 0x20000: profiling aid, skip phase 1
   const size_t lbase = ((size_t)n * nstrips + strip) * m.T;
   // edge functions are affine in the pixel index: w_k(i+1, j) = w_k(i, j) + 16*dwx_k, so a row costs three integer adds
   // per cell after one evaluation at its first cell (`first`/`step` stride the cells of a row-major walk over lanes)
   auto raster_cells = [&](const TriSetup& tr, float iw0, float iw1, float iw2, int t, int i0, int i1, int j0, int j1,
                           int first, int step) {
-    if (flags & 0x40000) return;   // profiling aid: setup only
+    if (FP_PROF_FLAG(flags, 0x40000)) return;   // profiling aid: setup only
     const float fE = (float)tr.area2;
     const int dx0 = -16 * (tr.y2 - tr.y1), dx1 = -16 * (tr.y0 - tr.y2), dx2 = -16 * (tr.y1 - tr.y0);
     auto cell = [&](int i, int j, int w0, int w1, int w2) {
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
       const float zc = fminf(z, FP_ZMAXF);
       const uint32_t zq = (uint32_t)rintf(zc * FP_ZSCALEF);
       const unsigned long long key = ((unsigned long long)zq << 32) | (uint32_t)t;
-      if (flags & 0x80000) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32))); }   // profiling aid: no LDS atomic
+      if (FP_PROF_FLAG(flags, 0x80000)) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32))); }   // profiling aid: no LDS atomic
       else atomicMin(&zb[(j - row0) * ow + i], key);
     };
     if (step == 1) {            // one lane owns the whole box: incremental walk
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
     const bool covered = key != FP_KEY_EMPTY;
     float col[3] = {0.f, 0.f, 0.f}, pt[3] = {0.f, 0.f, 0.f}, nm[3] = {0.f, 0.f, 0.f};
     int tid_out = -1;
-    if (covered && !(flags & 0x10000)) {   // 0x10000: profiling aid, skip the shading gathers
+    if (covered && !FP_PROF_FLAG(flags, 0x10000)) {   // 0x10000: profiling aid, skip the shading gathers
       const int t = (int)(uint32_t)(key & 0xFFFFFFFFull);
       tid_out = t;
       const int fa0 = m.faces[t * 3], fa1 = m.faces[t * 3 + 1], fa2 = m.faces[t * 3 + 2];
@@ -519,6 +529,7 @@ extern "C" int fp_render_crops(const fp_mesh* mesh, const float* poses, const fl
                                float* normal, uint32_t* zbuf, int32_t* tri_id, void* workspace,
                                size_t workspace_bytes, void* stream) {
   FP_REQUIRE(N >= 0, "fp_render_crops: N < 0");
+  FP_REQUIRE((flags & ~FP_RENDER_FLAG_MASK) == 0, "fp_render_crops: unknown flag bits 0x%x", flags & ~FP_RENDER_FLAG_MASK);
   if (N == 0) return FP_OK;
   FP_REQUIRE(mesh && poses && K9, "fp_render_crops: NULL mesh/poses/K");
   FP_REQUIRE(oh > 0 && ow > 0 && oh <= 1024 && ow <= 1024, "fp_render_crops: output size %dx%d unsupported (max 1024)", oh, ow);

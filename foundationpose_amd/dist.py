@@ -28,10 +28,13 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
-def all_gather_rows(local, n_total, group=None):
+def all_gather_rows(local, n_total, group=None, collective=None, world_rank=None):
     """local: this rank's shard (n_local, C) of a row-sharded (n_total, C) tensor (sharding = shard_bounds).
-    Returns the full tensor on every rank with ONE all-gather (short shards are padded to the common chunk size)."""
-    world, rank = _world(group)
+    Returns the full tensor on every rank with ONE all-gather (short shards are padded to the common chunk size).
+    collective(out, send): the all-gather itself (default torch.distributed.all_gather_into_tensor on `group`);
+    world_rank=(world, rank) overrides the process group's -- both exist so that tests can run the G ranks of a node one
+    after the other on one GPU with everything else (padding, stripping, ordering) being the code that runs on RCCL."""
+    world, rank = world_rank if world_rank is not None else _world(group)
     if world == 1:
         if local.shape[0] != n_total:
             raise ValueError(f"all_gather_rows: single process holds {local.shape[0]} rows, expected {n_total}")
@@ -47,7 +50,10 @@ def all_gather_rows(local, n_total, group=None):
         pad = send[-1:].expand(chunk - (e - b), C) if e > b else torch.zeros((chunk, C), dtype=local.dtype, device=local.device)
         send = torch.cat([send, pad], dim=0)
     out = torch.empty((world * chunk, C), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, send, group=group)
+    if collective is not None:
+        collective(out, send)
+    else:
+        dist.all_gather_into_tensor(out, send, group=group)
     if world * chunk == n_total:
         return out
     return torch.cat([out[r * chunk:r * chunk + (be - bb)] for r, (bb, be) in enumerate(bounds)], dim=0)
@@ -58,32 +64,33 @@ class FeaturePoseExchange:
     features of the local shard; all-gathers [feature (512) | refined pose (16)] records and keeps the gathered
     poses in ``poses_all``.  Records travel as float32 (528 floats/hypothesis, 532 KB at N=252)."""
 
-    def __init__(self, poses_local, n_total, group=None):
+    def __init__(self, poses_local, n_total, group=None, collective=None, world_rank=None):
         self.poses_local = poses_local.reshape(-1, 16)
         self.n_total = n_total
         self.group = group
+        self.collective, self.world_rank = collective, world_rank      # see all_gather_rows
         self.poses_all = None
 
     def __call__(self, feats_local):
         rec = torch.cat([feats_local.float(), self.poses_local.float()], dim=1)
-        full = all_gather_rows(rec, self.n_total, self.group)
+        full = all_gather_rows(rec, self.n_total, self.group, self.collective, self.world_rank)
         D = feats_local.shape[1]
         self.poses_all = full[:, D:].reshape(-1, 4, 4).contiguous()
         return full[:, :D].to(feats_local.dtype).contiguous()
 
 
 def register_hypothesis_parallel(refiner, scorer, rgb, depth, K, poses_all, xyz_map, mesh=None, mesh_tensors=None,
-                                 mesh_diameter=None, iteration=5, group=None):
+                                 mesh_diameter=None, iteration=5, group=None, collective=None, world_rank=None):
     """estimater.py:214-229 (refine all hypotheses, score them, sort) with the hypotheses sharded over the ranks.
     ``poses_all`` (N,4,4) is the same on every rank.  Returns (poses sorted by score (N,4,4), scores sorted (N,),
-    order) -- replicated on every rank."""
-    world, rank = _world(group)
+    order) -- replicated on every rank.  collective / world_rank: see all_gather_rows."""
+    world, rank = world_rank if world_rank is not None else _world(group)
     poses_all = torch.as_tensor(poses_all)
     N = poses_all.shape[0]
     b, e = shard_bounds(N, world)[rank]
     local, _ = refiner.predict(rgb, depth, K, poses_all[b:e], xyz_map, mesh=mesh, mesh_tensors=mesh_tensors,
                                mesh_diameter=mesh_diameter, iteration=iteration)
-    ex = FeaturePoseExchange(local, N, group)
+    ex = FeaturePoseExchange(local, N, group, collective, world_rank)
     scores, _ = scorer.predict(rgb, depth, K, local, mesh=mesh, mesh_tensors=mesh_tensors,
                                mesh_diameter=mesh_diameter, feature_exchange=ex)
     order = scores.argsort(descending=True)

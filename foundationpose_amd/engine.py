@@ -26,6 +26,11 @@ score_network.py:73-74), and attention never materialises the (N*4,400,400) prob
 No PyTorch compute kernel is left on this plan (allocations only).
 
 precision='fp32' is the fp32 parity configuration: plain torch ops, no autocast.
+
+precision='torch_amp' is BASELINE configs[1] taken literally -- "HIP rasteriser + PyTorch-ROCm refine/score": the nn.Module
+itself (refine_network.py / score_network.py, the reference's module tree) under torch.autocast('cuda', float16), i.e.
+MIOpen / rocBLAS / ATen kernels behind the same predictor.  It is the independent third implementation of the autocast
+policy that tests/test_gpu_amp.py puts next to the HIP plan and the oracle, and `bench.py --precision torch_amp`.
 """
 import torch
 import torch.nn.functional as F
@@ -292,6 +297,11 @@ class _HipEncoderLayer:
         return ops.colmean_f16(ff, self.n2[0], self.n2[1], 1e-5, resid32=y32)    # mean_t LN(y + ff)
 
 
+def _check_precision(precision):
+    if precision not in ("fp16", "fp32", "torch_amp"):
+        raise ValueError(f"precision must be 'fp16', 'fp32' or 'torch_amp', got {precision!r}")
+
+
 def _dev_sd(module_or_sd, device):
     sd = module_or_sd.state_dict() if hasattr(module_or_sd, "state_dict") else module_or_sd
     return {k: v.detach().to(device) for k, v in sd.items()}
@@ -299,9 +309,13 @@ def _dev_sd(module_or_sd, device):
 
 class RefinePlan:
     def __init__(self, model, device, precision="fp16", channels_last=True):
-        sd = _dev_sd(model, device)
+        _check_precision(precision)
         self.dtype = torch.float16 if precision == "fp16" else torch.float32
         self.hip = self.dtype == torch.float16
+        self.module = model if precision == "torch_amp" else None
+        if self.module is not None:
+            return
+        sd = _dev_sd(model, device)
         self.heads = {}
         if self.hip:
             self.enc = _HipEncoder(sd, "encodeA", "encodeAB", device)
@@ -319,6 +333,11 @@ class RefinePlan:
         """AB (2N,6,H,W) in the plan's dtype -> {'trans': (N,3) f32, 'rot': (N,3|6) f32}.  slot: activation-buffer set
         (callers that overlap on different streams use different slots)"""
         out = {}
+        if self.module is not None:
+            n = AB.shape[0] // 2
+            with torch.autocast("cuda", dtype=torch.float16):          # predict_pose_refine.py:190-191
+                o = self.module(AB[:n], AB[n:])
+            return {k: v.float() for k, v in o.items()}                 # predict_pose_refine.py:192-193
         if self.hip:
             tok16, x16 = self.enc(AB, slot)
             for name, (layer, head) in self.heads.items():
@@ -334,9 +353,13 @@ class RefinePlan:
 
 class ScorePlan:
     def __init__(self, model, device, precision="fp16", channels_last=True):
-        sd = _dev_sd(model, device)
+        _check_precision(precision)
         self.dtype = torch.float16 if precision == "fp16" else torch.float32
         self.hip = self.dtype == torch.float16
+        self.module = model if precision == "torch_amp" else None
+        if self.module is not None:
+            return
+        sd = _dev_sd(model, device)
         if self.hip:
             self.enc = _HipEncoder(sd, "encoderA", "encoderAB", device)
             self.att = _HipMHA(sd, "att", fp16_scores=True)
@@ -352,6 +375,14 @@ class ScorePlan:
     def features(self, AB, slot=0, out=None):
         """(2n,6,H,W) -> pooled per-hypothesis features (n,512), fp16 on the HIP plan (score_network.py:60-74); written
         into `out` if given (HIP plan)"""
+        if self.module is not None:
+            n = AB.shape[0] // 2
+            with torch.autocast("cuda", dtype=torch.float16):          # predict_score.py:193-194 -> score_network.py:60-74
+                f = self.module.extract_feat(AB[:n], AB[n:])
+            if out is not None:
+                out.copy_(f)
+                return out
+            return f
         if self.hip:
             _, x16 = self.enc(AB, slot)
             # out_proj and the token mean commute (score_network.py:73-74): pool the attention output, project N rows
@@ -366,6 +397,10 @@ class ScorePlan:
     def head(self, feats, L):
         """cross-hypothesis attention + linear (score_network.py:83-88): feats (bs*L,512) -> logits (bs,L) fp32"""
         x = feats.reshape(-1, L, feats.shape[-1])
+        if self.module is not None:
+            with torch.autocast("cuda", dtype=torch.float16):          # score_network.py:83-88
+                x, _ = self.module.att_cross(x, x, x)
+                return self.module.linear(x).reshape(-1, L).float()
         if self.hip:
             if x.dtype != torch.float16:           # features that came back from an all-gather in another dtype
                 x = x.to(torch.float16)

@@ -12,6 +12,7 @@ MODE_REFINE = 0
 MODE_SCORE = 1
 ROT_AXIS_ANGLE = 0
 ROT_6D = 1
+TRANS_TRACKNET, TRANS_DEEPIM, TRANS_RAW = 0, 1, 2
 
 
 def _stream(t=None):
@@ -136,6 +137,9 @@ def _workspace(nbytes, device):
     """library-side default scratch: one per (device, stream) -- launches on different streams may overlap"""
     if nbytes == 0:
         return None
+    if torch.cuda.is_current_stream_capturing():
+        # an allocation made here would come from the capturing graph's private pool and then be cached process-wide
+        raise _lib.FpAmdError("render_crops inside a stream capture needs a caller-owned `workspace` (ops.workspace_bytes)")
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -215,7 +219,8 @@ def warp_crops(rgb, xyz_map, depth, tf_to_crops, K, poses, mesh_diameter, mode, 
 def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, trans_normalizer=(1.0, 1.0, 1.0),
                 rot_normalizer=1.0, mesh_diameter=1.0, out=None, trans_delta_out=None, rot_delta_out=None, trans_rep="tracknet",
                 K=None, tf_to_crops=None, input_w=0):
-    """fp_pose_update.  trans_rep='deepim' needs K, tf_to_crops (N,3,3) and the crop width (predict_pose_refine.py:201-215)"""
+    """fp_pose_update.  trans_rep='deepim' needs K, tf_to_crops (N,3,3) and the crop width (predict_pose_refine.py:201-215);
+    any trans_rep other than 'tracknet' / 'deepim' is the reference's plain `else` branch (:217-218): the raw output"""
     tr = _dev(trans, torch.float32, "trans")
     ro = _dev(rot, torch.float32, "rot")
     P = _dev(poses, torch.float32, "poses")
@@ -234,7 +239,8 @@ def pose_update(trans, rot, poses, rot_rep="axis_angle", normalize_xyz=True, tra
     st = _lib.lib().fp_pose_update(_ptr(tr), _ptr(ro), _ptr(P), rr, int(bool(normalize_xyz)),
                                    tn.ctypes.data_as(C.c_void_p), float(rot_normalizer), float(np.float32(mesh_diameter)),
                                    N, _ptr(O), _ptr(_dev(trans_delta_out, torch.float32, "trans_delta_out")),
-                                   _ptr(_dev(rot_delta_out, torch.float32, "rot_delta_out")), 1 if deepim else 0,
+                                   _ptr(_dev(rot_delta_out, torch.float32, "rot_delta_out")),
+                                   TRANS_DEEPIM if deepim else (TRANS_TRACKNET if trans_rep == "tracknet" else TRANS_RAW),
                                    K9.ctypes.data_as(C.c_void_p) if deepim else None, _ptr(tf), float(input_w), _stream(P))
     _lib.check(st, "fp_pose_update")
     return O

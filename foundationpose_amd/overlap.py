@@ -12,7 +12,13 @@ The fork / join edges are stream waits on events (torch.cuda.Stream.wait_stream)
 capture.  Every buffer a sub-batch touches is its own: the encoder's activation sets are keyed by `slot`, the rasteriser
 scratch by stream (ops._workspace) or passed per part by the caller.
 """
+import logging
+import os
+
+import numpy as np
 import torch
+
+log = logging.getLogger(__name__)
 
 
 # side streams are shared by every predictor of the process (one list per device): ROCm maps HIP streams onto a handful
@@ -35,35 +41,95 @@ def reserve_streams(device, k=1):
         with torch.cuda.stream(st):                  # first use: the runtime binds a stream to its hardware queue lazily
             torch.zeros(1, device=device)
         side.append(st)
-        _OVERLAPS[(idx, len(side) - 1)] = _overlaps_with_current(st, device)
+        force = os.environ.get("FP_AMD_OVERLAP", "").strip()      # "0" / "1": skip the probes and force the decision
+        if force in ("0", "1"):
+            ok, why = force == "1", "forced by FP_AMD_OVERLAP"
+        else:
+            ok = _overlaps_with_current(st, device)
+            why = "side stream runs beside the main stream" if ok else "side stream shares the main stream's hardware queue"
+            if ok and not _exact_next_to_gemm(st, device):
+                ok, why = False, "CANARY FAILED: the rasteriser is not bit-exact next to a GEMM on another stream"
+        log.info("overlap: side stream %d of cuda:%d %s (%s)", len(side) - 1, idx, "enabled" if ok else "disabled", why)
+        _OVERLAPS[(idx, len(side) - 1)] = ok
     return side[:k]
 
 
 _OVERLAPS = {}
 
 
-def _overlaps_with_current(st, device, cycles=400_000):
+def _overlaps_with_current(st, device, cycles=400_000, repeats=3):
     """does work on `st` run beside work on the current stream?  Two spin kernels, one per stream, against one alone
-    (about 1 ms, once per side stream).  A stream that landed on the main stream's hardware queue serialises with it."""
+    (about 1 ms each; the median of `repeats` measurements, once per side stream).  A stream that landed on the main
+    stream's hardware queue serialises with it."""
     if torch.cuda.is_current_stream_capturing():
         return True                                  # cannot measure inside a capture; the eager warm-up has done it
     main = torch.cuda.current_stream(device)
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     torch.cuda._sleep(cycles)                        # warm the spin kernel
-    torch.cuda.synchronize(device)
-    e[0].record(main)
-    torch.cuda._sleep(cycles)
-    e[1].record(main)
-    st.wait_stream(main)
-    e[2].record(main)
-    with torch.cuda.stream(st):
+    ratios = []
+    for _ in range(repeats):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        torch.cuda.synchronize(device)
+        e[0].record(main)
         torch.cuda._sleep(cycles)
-    torch.cuda._sleep(cycles)
-    main.wait_stream(st)
-    e[3].record(main)
+        e[1].record(main)
+        st.wait_stream(main)
+        e[2].record(main)
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(cycles)
+        torch.cuda._sleep(cycles)
+        main.wait_stream(st)
+        e[3].record(main)
+        torch.cuda.synchronize(device)
+        ratios.append(e[2].elapsed_time(e[3]) / max(e[0].elapsed_time(e[1]), 1e-6))
+    return sorted(ratios)[len(ratios) // 2] < 1.5
+
+
+def _exact_next_to_gemm(st, device, launches=24):
+    """Canary for the one way concurrent streams were ever seen to change a result (on MI355X / ROCm 7.2 a
+    build of the rasteriser WITH packed-fp32 VALU instructions returned wrong lanes while an MFMA kernel of another stream
+    shared the chip; the library is built without them and csrc/Makefile checks the objects).  Before sub-batches are
+    allowed to overlap, the rasteriser runs `launches` times beside a GEMM on the side stream and every output must be
+    bit-identical to the launch that ran alone (~10 ms, once per process and device).  A failure disables the overlap --
+    results stay right, the step gets slower -- and is logged as an error."""
+    if torch.cuda.is_current_stream_capturing():
+        return True
+    from . import ops, synthetic as syn
+    from .Utils import get_mesh_handle, make_mesh_tensors
+    from .mesh import make_can_mesh
+    mesh = make_can_mesh()
+    gm = make_mesh_tensors(mesh, device=device)      # keeps the device tensors of the handle alive for the duration
+    h = get_mesh_handle(gm)
+    n = 38
+    T = syn.gt_pose(0).astype(np.float32)
+    P = torch.as_tensor(syn.perturbed_poses(T, n, seed=3, max_trans=0.01, max_rot_deg=170.0).astype(np.float32), device=device)
+    diam = float(np.linalg.norm(mesh.vertices.max(0) - mesh.vertices.min(0)))
+    _, bb = ops.crop_windows(P, syn.YCBV_K, diam, 1.2, (160, 160))
+    A = torch.zeros((n, 6, 160, 160), dtype=torch.float16, device=device)
+    ws = torch.empty(max(16, ops.workspace_bytes(n, h.V, h.T, 160, 160)), dtype=torch.uint8, device=device)
+    x = torch.randn((14800, 512), device=device, dtype=torch.float16)
+    w = torch.randn((512, 512), device=device, dtype=torch.float16)
+    y = torch.empty((14800, 512), device=device, dtype=torch.float16)
+
+    def render():
+        return ops.render_crops(h, P, bb, syn.YCBV_K, syn.H, syn.W, out_hw=(160, 160), mesh_diameter=diam, xyz_thr=0.001,
+                                normalize_xyz=True, A_out=A, workspace=ws, want=("A",))["A"]
+    base = render().clone()
+    torch.matmul(x, w.t(), out=y)                     # warm rocBLAS outside the measured overlap
     torch.cuda.synchronize(device)
-    alone, pair = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
-    return pair < 1.5 * alone
+    main = torch.cuda.current_stream(device)
+    bad = 0
+    for _ in range(launches):
+        st.wait_stream(main)
+        r = render()
+        with torch.cuda.stream(st):
+            torch.matmul(x, w.t(), out=y)
+        main.wait_stream(st)
+        bad += int(not torch.equal(r, base))
+    torch.cuda.synchronize(device)
+    if bad:
+        log.error("overlap canary: %d of %d rasteriser launches next to a GEMM differ from the launch that ran alone; "
+                  "sub-batches will NOT overlap on this device", bad, launches)
+    return bad == 0
 
 
 def side_streams_overlap(device, k=1):

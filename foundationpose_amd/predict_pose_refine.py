@@ -186,8 +186,10 @@ class PoseRefinePredictor:
         if workspace is not None and len(workspace) != len(parts):
             raise ValueError(f"refine_device: {len(parts)} parts need {len(parts)} workspaces, got {len(workspace)}")
         outs = self.alloc_outputs(N, dev) + (int(iteration),)
-        if iteration <= 0:
+        if iteration <= 0:          # no update happened: the pose unchanged, a zero translation and an identity rotation delta
             outs[0].copy_(poses)
+            outs[1].zero_()
+            outs[2].copy_(torch.eye(3, dtype=torch.float32, device=dev).expand(N, 3, 3))
         streams = self.sub.streams(dev, len(parts))
         self.sub.fork(streams)
         state = [None] * len(parts)

@@ -44,8 +44,9 @@ typedef enum {
 /* fp_pose_update rot_rep / trans_rep */
 #define FP_ROT_AXIS_ANGLE 0
 #define FP_ROT_6D 1
-#define FP_TRANS_TRACKNET 0 /* cfg['trans_rep'] = 'tracknet' (the released configuration) and the plain `else` branch */
+#define FP_TRANS_TRACKNET 0 /* cfg['trans_rep'] = 'tracknet' (the released configuration), predict_pose_refine.py:195-199 */
 #define FP_TRANS_DEEPIM 1   /* 'deepim': crop-space shift of the projected centre + depth ratio, predict_pose_refine.py:201-215 */
+#define FP_TRANS_RAW 2      /* any other trans_rep: the plain `else` branch (:217-218), the raw output (x diameter/2 if normalize_xyz) */
 
 /* integer z-buffer definition; shared with oracle/fp_oracle.c */
 #define FP_SUBPIXEL_BITS 4

@@ -72,6 +72,9 @@ def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_np, mesh_di
             dt = ops.deepim_trans_delta(out["trans"].numpy(), poses, K, tf, cfg["input_resize"][0], bool(cfg["normalize_xyz"]), mesh_diameter)
             # the C pose update with an identity translation scale: normalize_xyz=True multiplies by diameter/2 = 1
             poses = ops.pose_update(dt, out["rot"].numpy(), poses, cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]), 2.0)
+        elif cfg.get("trans_rep", "tracknet") != "tracknet" and not cfg["normalize_xyz"]:   # plain else, predict_pose_refine.py:217-218
+            # raw output as the translation: the C pose update with normalize_xyz=True and diameter 2 multiplies by 1
+            poses = ops.pose_update(out["trans"].numpy(), out["rot"].numpy(), poses, cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]), 2.0)
         else:
             poses = ops.pose_update(out["trans"].numpy(), out["rot"].numpy(), poses, cfg["rot_rep"],
                                     bool(cfg["normalize_xyz"]), tn, float(cfg["rot_normalizer"]), float(mesh_diameter))

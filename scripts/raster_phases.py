@@ -1,3 +1,6 @@
+"""phase timing of fp_render_crops with the phase-skip flag bits that exist only in the profiling build:
+    make -C foundationpose_amd/csrc profile && FP_AMD_LIB=foundationpose_amd/csrc/libfp_amd_profile.so python scripts/raster_phases.py
+(the product library rejects these bits: FP_ERR_INVALID_ARG)"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np

@@ -58,6 +58,13 @@ def test_argument_errors_are_reported_without_gpu():
     assert lib.fp_layernorm_res_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,
                                     C.c_void_p(16), None, 4, 512, None) == -1     # residual given twice
     assert lib.fp_attention_f16_fwd(C.c_void_p(16), C.c_void_p(16), 1, 4, 4, 128, 2, None) == -1
+    # fp_render_crops defines two flag bits; anything else (e.g. the phase-skip bits of the profiling build) is refused
+    for bad in (0x10000, 0x80000, 4):
+        assert lib.fp_render_crops(None, None, None, None, 480, 640, 0, 160, 160, 0.8, 0.5, 0.17, 0.001, 3 | bad, None, None, None, None,
+                                   None, None, None, None, 0, None) == -1
+        assert b"unknown flag bits" in lib.fp_last_error()
+    assert lib.fp_render_crops(None, None, None, None, 480, 640, 0, 160, 160, 0.8, 0.5, 0.17, 0.001, 3, None, None, None, None,
+                               None, None, None, None, 0, None) == 0       # N == 0: nothing to do
 
 
 def test_product_does_not_import_oracle():

@@ -4,8 +4,9 @@ the matched-dtype oracle (oracle/nets_amp.py, pinned against the reference's mod
      fp32-summation-order flips (tests/amp_util.py);
   2. encoder / plans against the oracle on the same inputs;
   3. BASELINE size: 252 hypotheses -- each of 5 refine iterations from bit-identical poses (teacher forced, calibrated
-     stand-in weights), the free-running 5-iteration chain (contraction-scaled heads, weights.CONTRACTION_HEAD_SCALE)
-     and the 252 scores (Kendall tau, top-1).  The measured error distributions are written to
+     stand-in weights) as a THREE-way comparison HIP plan / the nn.Module under torch.autocast on PyTorch-ROCm / oracle,
+     the free-running 5-iteration chain (contraction-scaled heads, weights.CONTRACTION_HEAD_SCALE) and the 252 scores
+     (Kendall tau, top-1), also three ways.  The measured error distributions are written to
      gpurun_out/parity_amp.json (committed under profiles/)."""
 import json
 import os
@@ -340,12 +341,20 @@ def _pct(x):
     return dict(median=float(np.median(x)), p90=float(np.percentile(x, 90)), p99=float(np.percentile(x, 99)), max=float(x.max()))
 
 
-def test_refiner_252_teacher_forced_against_amp_oracle(scene, dev, gmesh, frame):
-    """252 hypotheses, deployed fp16 plan, each of the 5 iterations started from the oracle's pose of the previous one
-    (bit-identical inputs), calibrated stand-in weights (|update| ~ 2 cm / 0.2 rad).  The error is compared with the
-    floor the oracle itself shows between two fp32 summation orders of the SAME policy (first 64 hypotheses of
-    iteration 0): with these weights the network output carries ~0.5 % of rounding noise, so 1e-4 rad is not reachable
-    by any two implementations of the autocast policy; the gate is 6x the floor."""
+def test_refiner_252_teacher_forced_three_way(scene, dev, gmesh, frame):
+    """252 hypotheses, calibrated stand-in weights (|update| ~ 2 cm / 0.2-0.36 rad), each of the 5 iterations started from
+    the oracle's pose of the previous one (bit-identical inputs), THREE implementations of the reference's autocast policy:
+      hip     the deployed plan: every network op on libfp_amd.so (precision='fp16')
+      lib     the product's nn.Module under torch.autocast('cuda', float16) on PyTorch-ROCm: MIOpen / rocBLAS / ATen
+              kernels (precision='torch_amp') -- nothing of it is ours
+      oracle  oracle/nets_amp.py on the CPU (explicit casts; pinned against the reference under CPU autocast)
+    The refined poses of the three are compared pairwise.  With these weights the policy itself carries ~0.3 % of the update
+    as fp16 rounding noise (each implementation rounds a different fp32 summation order), so 1e-4 rad is not reachable by
+    ANY pair -- the gate is that the HIP plan is as close to the oracle as the library is (x1.5 on median / p90: if all
+    three deviate independently by sigma from the exactly-rounded result, every pair is sqrt(2) sigma apart, but MIOpen's
+    fallback convolution here accumulates in float64, i.e. sigma_lib ~ 0, which makes lib-vs-oracle the smallest pair),
+    or inside the north-star 1e-4.  No slack against a self-made floor; the reversed-summation floor of the oracle against
+    itself is only reported."""
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
     from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
     from oracle import nets_amp, ops as oo
@@ -357,7 +366,7 @@ def test_refiner_252_teacher_forced_against_amp_oracle(scene, dev, gmesh, frame)
     trace = []
     op.refine_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, frame["xyz"], scene["mesh_np"], scene["diameter"],
                       iteration=5, trace=trace, amp=True)
-    # floor: same policy, reversed summation order, same inputs
+    # reported only: same policy, reversed summation order, same inputs
     nf = 64
     A, B = torch.from_numpy(trace[0]["A"][:nf]), torch.from_numpy(trace[0]["B"][:nf])
     nets_amp.REVERSED_SUMS = True
@@ -371,28 +380,41 @@ def test_refiner_252_teacher_forced_against_amp_oracle(scene, dev, gmesh, frame)
     floor_R = geodesic(p_r[:, :3, :3], trace[0]["poses"][:nf, :3, :3])
     floor_t = np.linalg.norm(p_r[:, :3, 3] - trace[0]["poses"][:nf, :3, 3], axis=1)
     t_oracle = time.time() - t0
-    pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16")
-    rep = dict(oracle_seconds=t_oracle, floor_dR=_pct(floor_R), floor_dt=_pct(floor_t), iterations=[])
+    preds = dict(hip=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16"),
+                 lib=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="torch_amp", n_streams=1))
+    rep = dict(oracle_seconds=t_oracle, oracle_reversed_sum_floor_dR=_pct(floor_R), oracle_reversed_sum_floor_dt=_pct(floor_t),
+               iterations=[], seconds=dict(hip=0.0, lib=0.0))
     start = P0
     for it in range(5):
-        out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], start, frame["xyz_t"], mesh=scene["mesh"],
-                              mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=1)
-        out = out.cpu().numpy()
         tgt = trace[it]["poses"]
-        dR, dt = geodesic(out[:, :3, :3], tgt[:, :3, :3]), np.linalg.norm(out[:, :3, 3] - tgt[:, :3, 3], axis=1)
+        out = {}
+        for name, pred in preds.items():
+            t1 = time.time()
+            o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], start, frame["xyz_t"], mesh=scene["mesh"],
+                                mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=1)
+            out[name] = o.cpu().numpy()
+            rep["seconds"][name] += time.time() - t1
+            raw = {k: v.cpu().numpy() for k, v in pred.last_raw_output.items()}
+            for k in ("trans", "rot"):            # the reference holds the raw outputs in fp16
+                assert np.array_equal(raw[k], raw[k].astype(np.float16).astype(np.float32)), (name, k)
+        out["oracle"] = tgt
         uR, ut = geodesic(tgt[:, :3, :3], start[:, :3, :3]), np.linalg.norm(tgt[:, :3, 3] - start[:, :3, 3], axis=1)
-        rep["iterations"].append(dict(dR=_pct(dR), dt=_pct(dt), update_dR=_pct(uR), update_dt=_pct(ut),
-                                      rel_dR=_pct(dR / np.maximum(uR, 1e-9)), rel_dt=_pct(dt / np.maximum(ut, 1e-9))))
-        # raw network outputs: fp16 values, within a few ulps + floor of the oracle's
-        raw = {k: v.cpu().numpy() for k, v in pred.last_raw_output.items()}
-        for k in ("trans", "rot"):
-            assert np.array_equal(raw[k], raw[k].astype(np.float16).astype(np.float32))
+        row = dict(update_dR=_pct(uR), update_dt=_pct(ut))
+        for a_, b_ in (("hip", "oracle"), ("lib", "oracle"), ("hip", "lib")):
+            dR = geodesic(out[a_][:, :3, :3], out[b_][:, :3, :3])
+            dt = np.linalg.norm(out[a_][:, :3, 3] - out[b_][:, :3, 3], axis=1)
+            row[f"{a_}_vs_{b_}"] = dict(dR=_pct(dR), dt=_pct(dt), rel_dR=_pct(dR / np.maximum(uR, 1e-9)), rel_dt=_pct(dt / np.maximum(ut, 1e-9)))
+        rep["iterations"].append(row)
         start = tgt
-    REPORT["refiner_252_teacher_forced"] = rep
+    REPORT["refiner_252_teacher_forced_three_way"] = rep
     for it, r in enumerate(rep["iterations"]):
-        assert r["dR"]["median"] <= 6 * max(rep["floor_dR"]["median"], 1e-5) and r["dR"]["max"] <= 6 * max(rep["floor_dR"]["max"], 1e-4), (it, r, rep["floor_dR"])
-        assert r["dt"]["median"] <= 6 * max(rep["floor_dt"]["median"], 1e-5) and r["dt"]["max"] <= 6 * max(rep["floor_dt"]["max"], 1e-4), (it, r, rep["floor_dt"])
-        assert r["rel_dR"]["median"] < 0.05 and r["rel_dt"]["median"] < 0.05, (it, r)
+        h, l = r["hip_vs_oracle"], r["lib_vs_oracle"]
+        for q, tol in (("dR", 1e-4), ("dt", 1e-4)):
+            for stat in ("median", "p90"):
+                assert h[q][stat] <= 1.5 * max(l[q][stat], tol), (it, q, stat, h[q], l[q])
+            assert h[q]["max"] <= 2.0 * max(l[q]["max"], tol), (it, q, h[q], l[q])
+        assert h["rel_dR"]["median"] < 0.01 and h["rel_dt"]["median"] < 0.02, (it, h)
+        assert r["update_dR"]["median"] > 0.05                 # full-size updates: nothing is scaled down
 
 
 def test_refiner_252_free_running_chain_and_scores(scene, dev, gmesh, frame):
@@ -440,7 +462,15 @@ def test_refiner_252_free_running_chain_and_scores(scene, dev, gmesh, frame):
     srep = dict(kendall_tau_vs_amp_oracle=tau, kendall_tau_fp32_oracle_vs_amp_oracle=tau_floor, top1_equal=bool(np.argmax(s) == np.argmax(sref)),
                 hip_top1_rank_in_oracle=int(np.argsort(-sref).tolist().index(int(np.argmax(s)))), abs_err=_pct(np.abs(s - sref)),
                 fp32_vs_amp_abs_err=_pct(np.abs(s32 - sref)), logit_std=float(sref.std()))
+    # third implementation: the nn.Module under torch.autocast on PyTorch-ROCm (MIOpen / rocBLAS / ATen)
+    lib = ScorePredictor(cfg=scfg, state_dict=ssd, device=dev, precision="torch_amp", n_streams=1)
+    sl, _ = lib.predict(scene["rgb"], frame["depth_t"], scene["K"], ref, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    sl = sl.cpu().numpy()
+    srep.update(kendall_tau_lib_vs_amp_oracle=kendall_tau(sl, sref), kendall_tau_hip_vs_lib=kendall_tau(s, sl),
+                lib_abs_err=_pct(np.abs(sl - sref)), hip_vs_lib_abs_err=_pct(np.abs(s - sl)), lib_top1_equal=bool(np.argmax(sl) == np.argmax(sref)))
     REPORT["scorer_252"] = srep
+    assert tau >= srep["kendall_tau_lib_vs_amp_oracle"] - 0.01, srep          # as close to the oracle as the library is
+    assert np.abs(s - sref).max() <= 1.5 * max(np.abs(sl - sref).max(), 0.02 * sref.std()), srep
     assert tau >= min(0.98, tau_floor - 0.01), srep
     assert srep["hip_top1_rank_in_oracle"] <= 2, srep
     assert np.abs(s - sref).max() <= max(4 * np.abs(s32 - sref).max(), 0.02 * sref.std()), srep
