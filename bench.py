@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="hypothesis sub-batches run on concurrent HIP streams (1: none)")
     ap.add_argument("--serialize", action="store_true", help="issue the sub-batches on ONE stream in the timed region too "
                     "(the launches of the per-kernel table; used for the rocprofv3 profile that table is checked against)")
+    ap.add_argument("--trace-markers", action="store_true", help="bracket the timed region with two marker launches (k_depth_to_xyz on a "
+                    "1 x 7 image) so that scripts/concurrent_roofline.py can cut it out of a rocprofv3 --kernel-trace of this command")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (instrumented) pass")
     args = ap.parse_args()
@@ -276,12 +278,20 @@ def main():
     sync()
     _log("timed region")
     clock = ClockSampler(local_rank)
+    marker_in = torch.ones((1, 7), dtype=torch.float32, device=dev)
+
+    def marker():       # outside the clock: the timed region below is exactly the K steps either way
+        if args.trace_markers:
+            ops.depth_to_xyz(marker_in, sc["K"])
+            torch.cuda.synchronize()
+    marker()
     with clock:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             rec = step()
         sync()
         dt = time.perf_counter() - t0
+    marker()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

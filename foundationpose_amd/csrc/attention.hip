@@ -305,8 +305,8 @@ extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, in
   FP_REQUIRE(H > 0 && ((((size_t)qkv | (size_t)out) & 15) == 0), "fp_attention_f16_fwd: bad head count / unaligned tensors");
   const long long wgs = (long long)B * H * ((S + 32 * AT_WAVES - 1) / (32 * AT_WAVES));
   FP_REQUIRE(wgs < (1ll << 31), "fp_attention_f16_fwd: too many workgroups");
-  FP_SET_MAX_LDS(k_attention_f16, AT_LDS);
   FP_REQUIRE((flags & ~FP_ATT_FP16_SCORES) == 0, "fp_attention_f16_fwd: unknown flags 0x%x", flags);
+  FP_SET_MAX_LDS(k_attention_f16, AT_LDS);
   const bool f16s = (flags & FP_ATT_FP16_SCORES) != 0;
   const float qscale = f16s ? (float)sqrt(1.0 / (double)head_dim) : 0.f;
   const float c = f16s ? 1.4426950408889634f : 1.4426950408889634f / sqrtf((float)head_dim);

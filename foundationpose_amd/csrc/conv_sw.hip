@@ -19,6 +19,8 @@
 // a k-step = memory cluster (12 fragment reads + this step's LDS-DMA) | barrier | 16 MFMAs | barrier; weights are
 // prefetched three k-steps ahead, the next chunk's patch is requested one piece per wave at taps 0-3 of the current chunk.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "igemm_common.h"
 #include "igemm_epilogue.h"
@@ -33,6 +35,10 @@ extern "C" int fp_dbg_conv_sw(unsigned long long* out, int reset) {
 #define SW_CLK(t) const unsigned long long t = wall_clock64()
 #else
 #define SW_CLK(t)
+#endif
+
+#ifndef SW_DEFAULT_VARIANT
+#define SW_DEFAULT_VARIANT 0
 #endif
 
 namespace {
@@ -254,6 +260,203 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv_sw_ls -- the same shifted-window convolution as a LOCK-STEP kernel with TWO workgroups per CU (round 3).
+// Why: k_conv_sw holds one 512-thread workgroup per CU, so nothing runs on the CU during a tile's cold start (first patch
+// + weights: ~4 us) and epilogue (~8 us) -- 16 % of a 256->256 tile, 29 % of a 128-channel tile; making the
+// kernel persistent serialised the same waves and was slower.  Here a workgroup is 4 waves (one per SIMD) on a 256 x 128
+// tile -- each wave still owns 128 x 64 outputs = 16 MFMAs per k-step, the intensity of the ping-pong kernel -- and its
+// LDS is exactly half of the CU's: two patch buffers of 448 rows x 64 B (double buffered across channel chunks) + a ring
+// of 3 weight stages of 128 x 64 B = 80 KiB.  Two workgroups are then resident per CU, unsynchronised with each other:
+// one's cold start / epilogue / fragment reads run under the other's MFMAs (the matrix pipe arbitrates by age, so two
+// workgroups that start in phase drift apart).  One workgroup barrier per k-step: at the top of k-step s every wave has
+// waited for its own pieces of W(s) (and of the chunk's patch), so past the barrier W(s) is visible to all and everyone
+// is done reading the buffers of k-step s-1, which is where W(s+2) and the next patch piece are sent.
+// The per-channel epilogue vectors do not fit beside the 80 KiB during the main loop; they are fetched into the (then
+// free) staging area at the start of the epilogue, under the other workgroup's main loop.
+constexpr int LS_PROWS = 448, LS_NSTW = 3;
+
+template <int BM, int BN, int TM>
+__global__ __launch_bounds__(256, 2) void k_conv_sw_ls(IgemmParams p) {
+  constexpr int BK = SW_BK, NW = 4, THREADS = 256;
+  constexpr int NWN = BN / 64;
+  static_assert((BM / (32 * TM)) * NWN == NW, "4 waves");
+  constexpr int ROWB = BK * 2;
+  constexpr int W_BYTES = BN * ROWB;
+  constexpr int PATCH_BYTES = LS_PROWS * ROWB;
+  constexpr int WI = BN / 16 / NW;                  // weight LDS-DMA instructions per wave and k-step
+  constexpr int PI = LS_PROWS / 16 / NW;            // patch instructions per wave and chunk: one at each of taps 0..PI-1
+  static_assert(WI >= 1 && PI >= 1 && PI <= 8 && LS_PROWS == PI * 16 * NW, "tile shape");
+  constexpr int STAGES_BYTES = 2 * PATCH_BYTES + LS_NSTW * W_BYTES;
+  static_assert(STAGES_BYTES >= BM * BN * 2 + BM * 16 + IG_BIAS_LDS, "the epilogue tile, its tables and the vectors reuse the staging area");
+  auto swz = [](int row) { return (row >> 2) & 3; };
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const patch = smem;
+  unsigned char* const wring = smem + 2 * PATCH_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / NWN, wn = wid - wm * NWN;
+
+  const int tiles_n = p.N / BN;
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (qd8 + 1) : r8 * (qd8 + 1) + (xcd - r8) * qd8) + loc;
+  const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int Cin = p.Cin, Ktot = 9 * Cin, Wp = p.in.Wp;
+  const int ncc = Cin / BK;
+
+  const int q0 = sw_q(p.in, m0);
+  const int qmax = (p.M / p.in.HoWo) * p.in.Hp * Wp - 1;
+  unsigned poff32[PI], woff32[WI];
+#pragma unroll
+  for (int j = 0; j < PI; ++j) {
+    const int row = (wid * PI + j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ swz(row);
+    int q = q0 + row;
+    q = q < qmax ? q : qmax;
+    poff32[j] = (unsigned)(((long long)q * p.in.cstride + p.in.coff + c * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    const int row = (wid * WI + j) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ swz(row);
+    woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Wt), 0, 0x7FFFFFFF, 0x00020000);
+
+  auto stage_patch = [&](int cc, int j) {
+    unsigned char* dst = patch + (cc & 1) * PATCH_BYTES + (wid * PI + j) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, (int)poff32[j],
+                                             cc * (BK * 2), 0, 0);
+  };
+  auto stage_w = [&](int cc, int tap, int slot) {
+    const int wsoff = (tap * Cin + cc * BK) * 2;
+    unsigned char* dst = wring + slot * W_BYTES + wid * (WI * 1024);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16,
+                                               (int)woff32[j], wsoff, 0, 0);
+  };
+
+  float16_ acc[2][TM];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int arow[TM], w_off[2][2];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    int m = m0 + wm * (32 * TM) + t * 32 + frow;
+    m = m < p.M ? m : p.M - 1;
+    arow[t] = sw_q(p.in, m) - q0;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rw = wn * 64 + t * 32 + frow;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) w_off[t][kk] = rw * ROWB + (((2 * kk + fhalf) ^ swz(rw)) << 4);
+  }
+
+  // ---- prologue: patch(0), W(0), W(1) requested
+#pragma unroll
+  for (int j = 0; j < PI; ++j) stage_patch(0, j);
+  stage_w(0, 0, 0);
+  stage_w(0, 1, 1);
+
+  // k-step s = (chunk cc, tap T); weight slot s % 3 = T % 3.  vmcnt at the top (loads retire in order): this wave's pieces
+  // of W(s) must have landed; younger and allowed in flight is what k-step s-1 sent: W(s+1) and its patch piece.
+  auto kstep = [&](int cc, auto tap_c, auto last_c, auto first_c) {
+    constexpr int T = decltype(tap_c)::value;
+    constexpr bool LAST = decltype(last_c)::value;     // last chunk: no next patch, the weight prefetch runs dry
+    constexpr bool FIRST = decltype(first_c)::value;   // k-step 0 of the tile: the prologue stands in for k-step -1
+    constexpr int ky = T / 3, kx = T - 3 * ky;
+    {
+      // previous k-step: tap T-1 of this chunk, or tap 8 of the chunk before (never the last chunk, no patch piece at tap 8)
+      constexpr bool prev_w = FIRST || T == 0 || !LAST || (T - 1) + 2 < 9;      // did k-step s-1 send W(s+1)?
+      constexpr bool prev_p = !FIRST && T >= 1 && !LAST && (T - 1) < PI;        // ... and a patch piece?
+      sw_wait_vm<(prev_w ? WI : 0) + (prev_p ? 1 : 0)>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) {
+      // the patch piece BEFORE the weights: waiting for W(s+2) two k-steps later then also covers this piece
+      if constexpr (T < PI) stage_patch(cc + 1, T);
+      if constexpr (T + 2 < 9) stage_w(cc, T + 2, (T + 2) % LS_NSTW);
+      else stage_w(cc + 1, T - 7, (T + 2) % LS_NSTW);
+    } else {
+      if constexpr (T + 2 < 9) stage_w(cc, T + 2, (T + 2) % LS_NSTW);
+    }
+    const unsigned char* pb = patch + (cc & 1) * PATCH_BYTES;
+    const unsigned char* wb = wring + (T % LS_NSTW) * W_BYTES;
+    const int shift = ky * Wp + kx;
+    half8 fa[2][TM], fw[2][2];
+    int a0[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      int ar = arow[t];
+      asm volatile("" : "+v"(ar));
+      const int pr = ar + shift;
+      a0[t] = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fa[0][t] = *reinterpret_cast<const half8*>(pb + a0[t]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fw[0][t] = *reinterpret_cast<const half8*>(wb + w_off[t][0]);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fa[1][t] = *reinterpret_cast<const half8*>(pb + (a0[t] ^ 32));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fw[1][t] = *reinterpret_cast<const half8*>(wb + w_off[t][1]);
+    __builtin_amdgcn_sched_barrier(0);   // all twelve fragment reads are requested before the first MFMA
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto chunk = [&](int cc, auto last_c, auto first_c) {
+    kstep(cc, std::integral_constant<int, 0>{}, last_c, first_c);
+    kstep(cc, std::integral_constant<int, 1>{}, last_c, std::false_type{});
+    kstep(cc, std::integral_constant<int, 2>{}, last_c, std::false_type{});
+    kstep(cc, std::integral_constant<int, 3>{}, last_c, std::false_type{});
+    kstep(cc, std::integral_constant<int, 4>{}, last_c, std::false_type{});
+    kstep(cc, std::integral_constant<int, 5>{}, last_c, std::false_type{});
+    kstep(cc, std::integral_constant<int, 6>{}, last_c, std::false_type{});
+    kstep(cc, std::integral_constant<int, 7>{}, last_c, std::false_type{});
+    kstep(cc, std::integral_constant<int, 8>{}, last_c, std::false_type{});
+  };
+  chunk(0, std::false_type{}, std::true_type{});                 // ncc >= 2 (Cin % 64 == 0)
+  for (int cc = 1; cc + 1 < ncc; ++cc) chunk(cc, std::false_type{}, std::false_type{});
+  chunk(ncc - 1, std::true_type{}, std::false_type{});
+  __syncthreads();                                               // every fragment read retired: the staging area is free
+  float* bias_lds = reinterpret_cast<float*>(smem + BM * BN * 2 + BM * 16);
+  ig_bias_to_lds(p, n0, bias_lds, wid, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // visible after the first barrier of the epilogue
+  ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
+}
+
+template <int BM, int BN, int TM>
+int sw_ls_launch(const IgemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 2 * LS_PROWS * SW_BK * 2 + LS_NSTW * BN * SW_BK * 2;
+  static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+  const long long tiles = (long long)fp_cdiv(p.M, BM) * (p.N / BN);
+  FP_REQUIRE(tiles < (1ll << 31), "fp_igemm_f16_fwd: too many tiles");
+  FP_SET_MAX_LDS((k_conv_sw_ls<BM, BN, TM>), LDS);
+  hipLaunchKernelGGL((k_conv_sw_ls<BM, BN, TM>), dim3((unsigned)tiles), dim3(256), LDS, stream, p);
+  FP_CHECK_LAUNCH("fp_igemm_f16_fwd(conv_sw_ls)");
+  return FP_OK;
+}
+
 template <int BM, int BN, int TM>
 int sw_launch(const IgemmParams& p, hipStream_t stream) {
   constexpr int LDS = ig_lds_main<BM, BN>(2 * sw_prows(BM) * SW_BK * 2 + SW_NSTW * BN * SW_BK * 2) + IG_BIAS_LDS;
@@ -270,7 +473,27 @@ int sw_launch(const IgemmParams& p, hipStream_t stream) {
 
 // The patch of a tile is the run of padded pixels from tap (0,0) of its first output pixel to tap (2,2) of its last:
 // BM - 1 + 2 per image-row crossing + 2 Wp + 2 per image crossing + 2 Wp + 3.  It has to fit the patch buffer.
-static int sw_tile_rows(const IgemmParams& p) { return (p.N % 256) == 0 ? 256 : 512; }
+static int sw_span(const IgemmGeom& g, int BM) {
+  const int row_cross = (BM - 1) / g.Wo + 1, img_cross = (BM - 1) / g.HoWo + 1;
+  return (BM - 1) + 2 * row_cross + (2 * g.Wp + 2) * img_cross + 2 * g.Wp + 3;
+}
+
+// which schedule: 1 = lock-step 256 x 128 tiles, two workgroups per CU (k_conv_sw_ls); 0 = ping-pong, one per CU
+static int sw_variant(const IgemmParams& p) {
+  int v = SW_DEFAULT_VARIANT;
+#ifdef FP_PROFILE_BUILD
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("FP_CONV_SW");          // profiling build only: ls | pp
+    forced = e ? (!strcmp(e, "ls") ? 1 : (!strcmp(e, "pp") ? 0 : -1)) : -1;
+  }
+  if (forced >= 0) v = forced;
+#endif
+  if (v == 1 && sw_span(p.in, 256) > LS_PROWS) v = 0;
+  return v;
+}
+
+static int sw_tile_rows(const IgemmParams& p) { return sw_variant(p) == 1 ? 256 : ((p.N % 256) == 0 ? 256 : 512); }
 
 bool fp_conv3x3_sw_applicable(const IgemmParams& p) {
   const IgemmGeom& g = p.in;
@@ -278,17 +501,16 @@ bool fp_conv3x3_sw_applicable(const IgemmParams& p) {
   if (g.HoWo % g.Wo != 0 || g.Wp != g.Wo + 2 || g.Hp != g.HoWo / g.Wo + 2) return false;
   const int BM = sw_tile_rows(p);
   if (p.M % g.HoWo != 0 || p.M < 2 * BM) return false;
-  if (p.Cin % SW_BK != 0 || p.N % 128 != 0) return false;
+  if (p.Cin % 64 != 0 || p.N % 128 != 0) return false;
   const long long bytes = (long long)(p.M / g.HoWo) * g.Hp * g.Wp * g.cstride * 2;
   if (bytes >= (1ll << 31)) return false;           // 32-bit byte offsets in the LDS-DMA source addresses
-  const int row_cross = (BM - 1) / g.Wo + 1, img_cross = (BM - 1) / g.HoWo + 1;
-  const int span = (BM - 1) + 2 * row_cross + (2 * g.Wp + 2) * img_cross + 2 * g.Wp + 3;
-  return span <= sw_prows(BM);
+  return sw_span(g, BM) <= (sw_variant(p) == 1 ? LS_PROWS : sw_prows(BM));
 }
 
 int fp_conv3x3_sw_tile_rows(const IgemmParams& p) { return sw_tile_rows(p); }
 
 int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream) {
+  if (sw_variant(p) == 1) return sw_ls_launch<256, 128, 4>(p, stream);
   if ((p.N % 256) == 0) return sw_launch<256, 256, 4>(p, stream);
   return sw_launch<512, 128, 4>(p, stream);
 }

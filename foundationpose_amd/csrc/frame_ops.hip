@@ -282,7 +282,7 @@ extern "C" int fp_pose_update(const float* trans, const float* rot, const float*
   if (N == 0) return FP_OK;
   FP_REQUIRE(trans && rot && poses_in && poses_out, "fp_pose_update: NULL tensor");
   FP_REQUIRE(rot_rep == FP_ROT_AXIS_ANGLE || rot_rep == FP_ROT_6D, "fp_pose_update: unknown rot_rep %d", rot_rep);
-  FP_REQUIRE(trans_rep == FP_TRANS_TRACKNET || trans_rep == FP_TRANS_DEEPIM, "fp_pose_update: unknown trans_rep %d", trans_rep);
+  FP_REQUIRE(trans_rep == FP_TRANS_TRACKNET || trans_rep == FP_TRANS_DEEPIM || trans_rep == FP_TRANS_RAW, "fp_pose_update: unknown trans_rep %d", trans_rep);
   FP_REQUIRE(trans_rep != FP_TRANS_DEEPIM || (K9 && tf_to_crops && input_w > 0.f),
              "fp_pose_update: trans_rep deepim needs K, tf_to_crops and the crop width");
   fp_k9 Kk = {{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}};

@@ -40,7 +40,7 @@ int fp_conv3x3_sw_tile_rows(const IgemmParams& p);
 // 4x2 MFMA tiles per wave (256x256 workgroup tile) halve the staged bytes per MFMA against 2x2 (128x128), and the
 // 128x128 variant makes up for it with two co-resident workgroups that fill each other's barrier and epilogue gaps.
 template <int BM, int BN, int TM, int NST, int BK>
-__global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, 1) void k_igemm_f16(IgemmParams p) {
+__global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, ((BM / (32 * TM)) * (BN / 64) == 4 && TM == 4) ? 2 : 1) void k_igemm_f16(IgemmParams p) {
   constexpr int NWN = BN / 64;
   constexpr int NW = (BM / (32 * TM)) * NWN;
   constexpr int THREADS = NW * 64;
@@ -237,6 +237,7 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
       if (!strcmp(e, "128x128")) forced = 1;
       else if (!strcmp(e, "256x128")) forced = 2;
       else if (!strcmp(e, "256x256")) forced = 3;
+      else if (!strcmp(e, "ls256x128")) forced = 4;   // 4 waves x (128 x 64), 3 stages of BK=32: two workgroups per CU
       else if (!strcmp(e, "pp256x256")) forced = 7;
       else if (!strcmp(e, "pp256x128")) forced = 9;
       else if (!strcmp(e, "generic")) forced = 100;   // default selection without the shifted-window kernel
@@ -263,6 +264,7 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
 #ifdef FP_PROFILE_BUILD
   if (sel == 2) return ig_launch<256, 128, 2, 3, 64>(p, stream);
   if (sel == 3) return ig_launch<256, 256, 4, 2, 64>(p, stream);
+  if (sel == 4) return ig_launch<256, 128, 4, 3, 32>(p, stream);
 #endif
   return ig_launch<128, 128, 2, 2, 64>(p, stream);
 }

@@ -32,10 +32,24 @@ itself (refine_network.py / score_network.py, the reference's module tree) under
 MIOpen / rocBLAS / ATen kernels behind the same predictor.  It is the independent third implementation of the autocast
 policy that tests/test_gpu_amp.py puts next to the HIP plan and the oracle, and `bench.py --precision torch_amp`.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
 from . import ops
+
+# MIOpen in this image has no tuned / pre-compiled gfx950 kernels for these layers and falls back to its naive reference
+# convolution (naive_conv_*_fwd_*: ~0.7 s per layer call at 504 images, measured in round 1; one fp32 pass of the encoder at
+# N=252 takes minutes).  The two torch configurations therefore run their convolutions on ATen's own path (im2col +
+# rocBLAS GEMM, what PyTorch uses when `torch.backends.cudnn` is disabled) unless MIOpen is asked for explicitly.
+USE_MIOPEN = False
+
+
+def _conv_backend():
+    if USE_MIOPEN or not torch.backends.cudnn.is_available():
+        return contextlib.nullcontext()
+    return torch.backends.cudnn.flags(enabled=False)
 
 
 def _bn_affine(sd, bn_p):
@@ -335,7 +349,7 @@ class RefinePlan:
         out = {}
         if self.module is not None:
             n = AB.shape[0] // 2
-            with torch.autocast("cuda", dtype=torch.float16):          # predict_pose_refine.py:190-191
+            with _conv_backend(), torch.autocast("cuda", dtype=torch.float16):          # predict_pose_refine.py:190-191
                 o = self.module(AB[:n], AB[n:])
             return {k: v.float() for k, v in o.items()}                 # predict_pose_refine.py:192-193
         if self.hip:
@@ -345,7 +359,8 @@ class RefinePlan:
                 # runs on N rows instead of N*400 (refine_network.py:90-91); the result is held in fp16 by the reference
                 out[name] = head(layer.pooled(tok16, x16, self.enc.pe), round_f16=True)
             return out
-        tok = self.enc(AB)
+        with _conv_backend():
+            tok = self.enc(AB)
         for name, (layer, w, b) in self.heads.items():
             out[name] = F.linear(layer(tok), w, b).float().mean(dim=1)
         return out
@@ -377,7 +392,7 @@ class ScorePlan:
         into `out` if given (HIP plan)"""
         if self.module is not None:
             n = AB.shape[0] // 2
-            with torch.autocast("cuda", dtype=torch.float16):          # predict_score.py:193-194 -> score_network.py:60-74
+            with _conv_backend(), torch.autocast("cuda", dtype=torch.float16):          # predict_score.py:193-194 -> score_network.py:60-74
                 f = self.module.extract_feat(AB[:n], AB[n:])
             if out is not None:
                 out.copy_(f)
@@ -387,7 +402,9 @@ class ScorePlan:
             _, x16 = self.enc(AB, slot)
             # out_proj and the token mean commute (score_network.py:73-74): pool the attention output, project N rows
             return self.att.out_rows(ops.colmean_f16(self.att.context(x16)), out_f16=True, out=out)
-        f = self.att(self.enc(AB)).float().mean(dim=1)
+        with _conv_backend():
+            tok = self.enc(AB)
+        f = self.att(tok).float().mean(dim=1)
         if out is not None:
             out.copy_(f)
             return out

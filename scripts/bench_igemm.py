@@ -11,7 +11,8 @@ from foundationpose_amd import ops
 dev = torch.device("cuda:0")
 N = int(os.environ.get("FP_N", "252"))
 G = ops.IgemmGeom
-tag = os.environ.get("FP_IGEMM_TILE", "default") + ("/profile-lib" if "profile" in os.environ.get("FP_AMD_LIB", "") else "")
+tag = os.environ.get("FP_IGEMM_TILE", "default") + "/" + os.path.basename(os.environ.get("FP_AMD_LIB", "libfp_amd.so")) + \
+    (":" + os.environ["FP_CONV_SW"] if "FP_CONV_SW" in os.environ else "") + f"/N={N}"
 
 
 def timeit(fn, reps=10):

@@ -379,6 +379,17 @@ def test_refiner_252_teacher_forced_three_way(scene, dev, gmesh, frame):
                          float(scene["diameter"]))
     floor_R = geodesic(p_r[:, :3, :3], trace[0]["poses"][:nf, :3, :3])
     floor_t = np.linalg.norm(p_r[:, :3, 3] - trace[0]["poses"][:nf, :3, 3], axis=1)
+    # which conv-bias policy does the library follow?  cuDNN / MIOpen add the bias to the rounded fp16 output ("separate", what
+    # the HIP plan and the oracle's default do); ATen's own convolution (im2col + GEMM, used here because MIOpen has no tuned
+    # gfx950 kernels in this image) starts the fp32 accumulation from the bias ("fused", one rounding, like the CPU backend).
+    # Evaluated on the same 64 hypotheses of iteration 0; the library is compared with BOTH below.
+    nets_amp.CONV_BIAS = "fused"
+    try:
+        o_f = nets_amp.refine_forward(A, B, sd)
+    finally:
+        nets_amp.CONV_BIAS = "separate"
+    p_fused = oo.pose_update(o_f["trans"].numpy(), o_f["rot"].numpy(), P0[:nf], cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]),
+                             float(scene["diameter"]))
     t_oracle = time.time() - t0
     preds = dict(hip=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16"),
                  lib=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="torch_amp", n_streams=1))
@@ -404,6 +415,14 @@ def test_refiner_252_teacher_forced_three_way(scene, dev, gmesh, frame):
             dR = geodesic(out[a_][:, :3, :3], out[b_][:, :3, :3])
             dt = np.linalg.norm(out[a_][:, :3, 3] - out[b_][:, :3, 3], axis=1)
             row[f"{a_}_vs_{b_}"] = dict(dR=_pct(dR), dt=_pct(dt), rel_dR=_pct(dR / np.maximum(uR, 1e-9)), rel_dt=_pct(dt / np.maximum(ut, 1e-9)))
+        if it == 0:     # the first 64 hypotheses against the oracle evaluated with the other bias policy
+            for name in ("hip", "lib"):
+                dRf = geodesic(out[name][:nf, :3, :3], p_fused[:, :3, :3])
+                dRs = geodesic(out[name][:nf, :3, :3], tgt[:nf, :3, :3])
+                row[f"{name}_first64_vs_oracle_bias_fused_dR"] = _pct(dRf)
+                row[f"{name}_first64_vs_oracle_bias_separate_dR"] = _pct(dRs)
+            rep["library_conv_bias_policy"] = "fused" if row["lib_first64_vs_oracle_bias_fused_dR"]["median"] < \
+                row["lib_first64_vs_oracle_bias_separate_dR"]["median"] else "separate"
         rep["iterations"].append(row)
         start = tgt
     REPORT["refiner_252_teacher_forced_three_way"] = rep
