@@ -256,6 +256,10 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
     const bool wide = (p.N % 256) == 0;
     const bool pp = wide && (p.M >= 150000 || p.N >= 1024 || (p.taps == 9 && p.Cin >= 256) || (p.taps == 1 && p.M < 75000 && p.M >= 4096));
     sel = pp ? 7 : 1;
+    // round 3 (profiles/r03_igemm_ab.log): the lock-step 256x128 tile with 4 waves of 128x64 and two workgroups per CU beats
+    // both for the stem's stride-2 conv (64->128: 0.59-0.61 against 0.53-0.55 PF/s) and for the QKV projection (0.73-0.74
+    // against 0.69-0.71); it loses on the 256->512 stride-2 conv and the 512-wide Linear layers at sub-batch size
+    if ((p.taps == 9 && p.in.stride == 2 && p.Cin <= 64) || (p.taps == 1 && p.N >= 1024)) sel = 4;
   }
   if (sel == 3 && (p.N % 256) != 0) sel = 2;
   if (sel == 7 && (p.N % 256) != 0) sel = 9;
@@ -264,8 +268,8 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
 #ifdef FP_PROFILE_BUILD
   if (sel == 2) return ig_launch<256, 128, 2, 3, 64>(p, stream);
   if (sel == 3) return ig_launch<256, 256, 4, 2, 64>(p, stream);
-  if (sel == 4) return ig_launch<256, 128, 4, 3, 32>(p, stream);
 #endif
+  if (sel == 4) return ig_launch<256, 128, 4, 3, 32>(p, stream);
   return ig_launch<128, 128, 2, 2, 64>(p, stream);
 }
 

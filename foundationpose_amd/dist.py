@@ -10,7 +10,11 @@ CPU tests).  The reference has no distributed code at all; this 
     two tiny cross layers redundantly, which leaves scores and poses replicated without a second collective.
 
 Both collectives move tens to hundreds of KB: latency-bound on xGMI, so they are single fused all-gathers enqueued on
-the compute stream, never rings of small messages.
+the compute stream, never rings of small messages.  "On the compute stream": a synchronous torch.distributed collective
+(async_op=False; distributed_c10d sets `AllgatherOptions.asyncOp = False` and does not call work.wait() -- "the backend
+has sync'ed at CPP level") is issued by ProcessGroupNCCL on the CURRENT stream in the PyTorch of this image (2.10), not on
+the group's side stream, so the exchange is ordered like any other kernel of the step and is captured into a hipGraph with
+it (tests/test_gpu_parity.py::test_rccl_all_gather_is_captured_with_the_compute_stream).
 """
 import torch
 import torch.distributed as dist

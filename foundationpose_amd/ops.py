@@ -434,6 +434,31 @@ class KernelTimers:
                              flops=float(sum(e[3] for e in evs) / n))
         return out
 
+    def busy(self, ref):
+        """for launches recorded on SEVERAL streams: per entry point the BUSY time = length of the union of its launches'
+        [start, end] intervals (timestamps relative to the event `ref`, recorded before the first launch), next to the sum of
+        the launch durations, total algorithmic bytes / flops and the span first start .. last end.
+        -> {name: dict(calls, sum_ms, busy_ms, bytes, flops, first_ms, last_ms)}"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            iv = sorted((ref.elapsed_time(a), ref.elapsed_time(b)) for a, b, _, _ in evs)
+            busy, cs, ce = 0.0, None, None
+            for a, b in iv:
+                if cs is None:
+                    cs, ce = a, b
+                elif a <= ce:
+                    ce = max(ce, b)
+                else:
+                    busy += ce - cs
+                    cs, ce = a, b
+            if cs is not None:
+                busy += ce - cs
+            out[name] = dict(calls=len(iv), sum_ms=float(sum(b - a for a, b in iv)), busy_ms=float(busy),
+                             bytes=float(sum(e[2] for e in evs)), flops=float(sum(e[3] for e in evs)),
+                             first_ms=float(iv[0][0]) if iv else 0.0, last_ms=float(max(b for _, b in iv)) if iv else 0.0)
+        return out
+
 
 def _esz(t):
     return t.element_size() if t is not None else 4

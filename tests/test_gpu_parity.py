@@ -739,10 +739,11 @@ def test_eight_hypothesis_shards_with_the_real_predictors_rank_like_one_batch(sc
     """SURVEY 8(e) hypothesis-parallel on ONE GPU: the 8 ranks of a node run one after the other -- the REAL
     PoseRefinePredictor / ScorePredictor on shards of 32, ..., 28 hypotheses (shard_bounds(252, 8)), the real
     register_hypothesis_parallel / FeaturePoseExchange / all_gather_rows with only the collective replaced by a copy
-    from the other ranks' send buffers -- and must rank the 252 hypotheses like the single 252-row batch.  Not a
-    tautology: a 32-row shard selects other GEMM tiles than the 252-row batch (conv_sw needs M >= 2 BM:
-    fp_conv3x3_sw_applicable), i.e. another fp32 summation order per hypothesis.  Contraction-scaled heads as in the
-    free-running chain test (an untrained refiner amplifies a last-bit difference 40-120x per iteration)."""
+    from the other ranks' send buffers -- and must rank the 252 hypotheses like the single 252-row batch.  Measured
+    (profiles/r03_shards8_vs_batch.json): refined poses and scores of the shards are BIT-IDENTICAL to the batch's -- at
+    these sizes a 28/32-row shard still selects the kernels and tiles of the 126-row sub-batches (fp_conv3x3_sw_applicable
+    only excludes M < 2 BM), and a tile's fp32 summation order does not depend on where it sits in the grid -- so sharding
+    changes nothing but the wall time.  Contraction-scaled heads as in the free-running chain test."""
     from foundationpose_amd import dist as fpd
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
     from foundationpose_amd.predict_score import ScorePredictor
@@ -792,6 +793,46 @@ def test_eight_hypothesis_shards_with_the_real_predictors_rank_like_one_batch(sc
                        max_abs_score_diff=float((s1 - s8).abs().max())), f)
     assert dt <= 1e-4 and dR <= 1e-4, (dt, dR)           # refined poses of the shards = those of the batch within the north-star tolerance
     assert tau >= 0.98 and top1_rank <= 1, (tau, top1_rank)
+
+
+_RCCL_CAPTURE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from foundationpose_amd import dist as fpd
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+s = torch.randn(252, device=dev); p = torch.randn(252, 4, 4, device=dev)
+fpd.gather_object_records(s, p); torch.cuda.synchronize()          # warm-up: communicator creation is not capturable
+side = torch.cuda.Stream()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.stream(side):
+    with torch.cuda.graph(g, stream=side):
+        rec = fpd.gather_object_records(s * 2, p + 1)                # the collective is enqueued on the capturing (compute) stream
+for k in range(3):
+    s.copy_(torch.randn(252, device=dev)); p.copy_(torch.randn(252, 4, 4, device=dev))
+    g.replay(); torch.cuda.synchronize()
+    assert rec.shape == (1, 252, 17)
+    assert torch.equal(rec[0, :, 0], s * 2) and torch.equal(rec[0, :, 1:].reshape(252, 4, 4), p + 1), k
+dist.destroy_process_group()
+print("RCCL_CAPTURE_OK")
+"""
+
+
+def test_rccl_all_gather_is_captured_with_the_compute_stream(dev):
+    """the result exchange is ONE all-gather enqueued on the compute stream, so that a whole step can live in a
+    hipGraph.  torch.distributed runs a synchronous collective (async_op=False -> AllgatherOptions.asyncOp = False) on the
+    CURRENT stream in this PyTorch; here RCCL (world size 1, own process) is captured into a graph on a side stream together
+    with the arithmetic around it and replayed with new inputs."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", _RCCL_CAPTURE, ROOT, str(port)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL_CAPTURE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_network_kernels_write_only_their_outputs(dev):
