@@ -21,6 +21,7 @@
 //   * V arrives [key][d] and is transposed while it is written to LDS (16-bit scatter, XOR-swizzled so that the
 //     fragment reads are conflict-free and the scatter is 2-way).
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 #include "fp_common.h"
 
 namespace {
@@ -42,52 +43,69 @@ constexpr int AT_LDS = 2 * AT_BUF;                // 66 KiB: two workgroups per 
 // the fragment reads; with the 136-byte rows both the 8-byte fragment reads and the 16-bit transposing scatter are 2-way
 __device__ __forceinline__ int vswz(int d) { return 4 * ((d >> 3) & 3); }
 
-constexpr int AT_WAVES = 8;                       // query tiles per workgroup: K / V of a head are staged (and V transposed) per
-                                                  // workgroup, so fewer, larger workgroups halve the LDS-write-bound scatter
-constexpr int AT_THREADS = AT_WAVES * 64;
+// LDS-DMA of 64 x 16 B, lane-linear destination.  A plain function on purpose: written inline in the kernel TEMPLATE the
+// address-space cast + builtin made hipcc 7.2 drop the kernel's host stub without a diagnostic (the object then has no
+// fat binary and the launch links against an undefined symbol).
+__device__ __forceinline__ void at_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+// Two shapes of the same kernel (round 3):
+//   QT = 1, 8 waves: one 32-query tile per wave, two waves per SIMD (rounds 1-2; 212 VGPRs)
+//   QT = 2, 4 waves: TWO query tiles per wave, one wave per SIMD with the whole 512-register file: every K and V^T fragment
+//       read from LDS feeds two MFMAs instead of one (the fragment reads were as long as the MFMAs they fed), the fragments
+//       of a whole block are in flight ahead of their use, and K / V of a head are staged by half as many waves.
+template <int QT, int WAVES>
+struct AtShape {
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int ROWS = 32 * QT * WAVES;     // query rows per workgroup
+};
 
 // qscale > 0 selects the fp16-score policy of the need_weights=True branch of F.multi_head_attention_forward under
 // autocast (score_network.py:73,86): q is multiplied by qscale = sqrt(1/d) and rounded to fp16, the q.k products are
 // rounded to fp16 before the fp32 softmax (c is then log2(e) alone).  qscale == 0: scaled_dot_product_attention.
-__global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
-                                                          int S, int H, float c /* log2(e)/sqrt(d) | log2(e) */, float qscale) {
+template <int QT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
+                                                                            int S, int H, float c /* log2(e)/sqrt(d) | log2(e) */, float qscale) {
+  constexpr int THREADS = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 31, hi = lane >> 5;
-  const int nqg = (S + 32 * AT_WAVES - 1) / (32 * AT_WAVES);   // query groups of 256 rows per (sequence, head)
+  const int nqg = (S + 32 * QT * WAVES - 1) / (32 * QT * WAVES);   // query groups per (sequence, head)
   const int qg = blockIdx.x % nqg, bh = blockIdx.x / nqg;
   const int h = bh % H, b = bh / H;
   const int ld = 3 * H * AT_D, ldo = H * AT_D;
   const _Float16* qp = qkv + (size_t)b * S * ld + h * AT_D;
   const _Float16* kp = qp + H * AT_D;
   const _Float16* vp = kp + H * AT_D;
-  const int q0 = (qg * AT_WAVES + wid) * 32;       // first query row of this wave
+  const int q0 = (qg * WAVES + wid) * (32 * QT);   // first query row of this wave
   const bool wave_active = q0 < S;                 // idle waves still help staging and keep the barriers matched
 
-  // ---- Q fragments (B operand): row q0 + lq, d = 16 kk + 8 hi + 0..7
-  half8 qf[8];
-  {
-    int qr = q0 + lq;
+  // ---- Q fragments (B operand): row q0 + 32 t + lq, d = 16 kk + 8 hi + 0..7
+  half8 qf[QT][8];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    int qr = q0 + 32 * t + lq;
     qr = qr < S ? qr : S - 1;
     const _Float16* src = qp + (size_t)qr * ld + 8 * hi;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const half8*>(src + 16 * kk);
+    for (int kk = 0; kk < 8; ++kk) qf[t][kk] = *reinterpret_cast<const half8*>(src + 16 * kk);
     if (qscale > 0.f) {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qf[kk][e] = (_Float16)((float)qf[kk][e] * qscale);
+        for (int e = 0; e < 8; ++e) qf[t][kk][e] = (_Float16)((float)qf[t][kk][e] * qscale);
     }
   }
 
-  // ---- staging.  K: LDS-DMA (buffer_load ... lds), 1 KiB = 4 keys per wave-instruction, 2 pieces per wave and block;
-  // the destination is lane-linear, so the XOR swizzle is applied to the SOURCE chunk: LDS chunk position (lane & 15)
-  // of key row k holds d-chunk (lane & 15) ^ (k & 15).  V: through registers (it has to be transposed), thread t owns
-  // chunks c = t + 512 i (i < 2): key = c % 8 + 8 (c / 128), d-chunk = (c / 8) % 16 (8 lanes = 8 consecutive keys).
+  // ---- staging.  K: LDS-DMA (buffer_load ... lds), 1 KiB = 4 keys per wave-instruction, 16 / WAVES pieces per wave and
+  // block; the destination is lane-linear, so the XOR swizzle is applied to the SOURCE chunk: LDS chunk position
+  // (lane & 15) of key row k holds d-chunk (lane & 15) ^ (k & 15).  V: through registers (it has to be transposed), thread t
+  // owns chunks c = t + THREADS i: key = c % 8 + 8 (c / 128), d-chunk = (c / 8) % 16 (8 lanes = 8 consecutive keys).
   const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kp), 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(vp), 0, 0x7FFFFFFF, 0x00020000);
-  constexpr int KPW = 16 / AT_WAVES;               // K pieces per wave and block
-  constexpr int VCH = 1024 / AT_THREADS;           // 16-byte V chunks per thread and block
+  constexpr int KPW = 16 / WAVES;                  // K pieces per wave and block
+  constexpr int VCH = 1024 / THREADS;              // 16-byte V chunks per thread and block
   // per-lane byte offsets inside a block, computed once; the block adds a scalar (blk * 64 rows).  Only a block that
   // reaches past the end of the sequence recomputes them with the row clamped (rows past the end are masked below,
   // any finite data will do).
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
   }
 #pragma unroll
   for (int i = 0; i < VCH; ++i) {
-    const int cidx = tid + AT_THREADS * i;
+    const int cidx = tid + THREADS * i;
     vkey[i] = (cidx & 7) + 8 * (cidx >> 7);
     voff[i] = vkey[i] * (ld * 2) + ((cidx >> 3) & 15) * 16;
   }
@@ -110,16 +128,14 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     if ((blk + 1) * AT_KB <= S) {
 #pragma unroll
       for (int i = 0; i < KPW; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
-                                                 16, koff[i], soff, 0, 0);
+        at_dma16(rsK, smem + buf * AT_BUF + (wid * KPW + i) * 1024, koff[i], soff);
 #pragma unroll
       for (int i = 0; i < VCH; ++i) rv[i] = __builtin_bit_cast(uint4_, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i], soff, 0));
     } else {
 #pragma unroll
       for (int i = 0; i < KPW; ++i) {
         const int back = max(blk * AT_KB + kkey[i] - (S - 1), 0) * (ld * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(smem + buf * AT_BUF + (wid * KPW + i) * 1024),
-                                                 16, koff[i] - back, soff, 0, 0);
+        at_dma16(rsK, smem + buf * AT_BUF + (wid * KPW + i) * 1024, koff[i] - back, soff);
       }
 #pragma unroll
       for (int i = 0; i < VCH; ++i) {
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     unsigned char* vb = smem + buf * AT_BUF + AT_K_BYTES;
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
-      const int cidx = tid + AT_THREADS * i;
+      const int cidx = tid + THREADS * i;
       const int key = (cidx & 7) + 8 * (cidx >> 7), dc = (cidx >> 3) & 15;
       const half8 v = __builtin_bit_cast(half8, rv[i]);
       unsigned char* dst = vb + (8 * dc) * AT_VROW + ((key ^ vswz(8 * dc)) << 1);   // vswz is constant over the 8 d of a chunk
@@ -141,12 +157,16 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     }
   };
 
-  float16_ o[4];                                   // O^T: d tile dt, lane = query
+  float16_ o[QT][4];                               // O^T: d tile dt, lane = query
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+  for (int t = 0; t < QT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m = -1e30f, l = 0.f;                       // running row max (raw scores) and row sum, per query = per lane pair
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][dt][r] = 0.f;
+  float m[QT], l[QT];                              // running row max (raw scores) and row sum, per query = per lane pair
+#pragma unroll
+  for (int t = 0; t < QT; ++t) { m[t] = -1e30f; l[t] = 0.f; }
 
   const int nblk = (S + AT_KB - 1) / AT_KB;
   stage_next(0, 0);
@@ -160,77 +180,23 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     const unsigned char* vb = kb + AT_K_BYTES;
     if (wave_active) {
       const int key0 = blk * AT_KB;
-      // ---- S^T tiles = K (2 x 32 keys) x Q^T: two independent accumulator chains
-      float16_ s0, s1;
+      // ---- S^T tiles = K (2 x 32 keys) x Q^T (QT x 32 queries): 2 QT independent accumulator chains
+      float16_ s[QT][2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[t][0][r] = 0.f; s[t][1][r] = 0.f; }
       const unsigned char* krp = kb + lq * 256;    // rows lq and 32 + lq share (row & 15)
-      half8 kf[2][2];
+      constexpr int KRING = 3;                     // fragment ring: the reads of the next KRING-1 k-steps are in flight
+      half8 kf[KRING][2];
       auto kread = [&](int kk, int slot) {
         const int pos = ((2 * kk + hi) ^ (lq & 15)) << 4;
         kf[slot][0] = *reinterpret_cast<const half8*>(krp + pos);
         kf[slot][1] = *reinterpret_cast<const half8*>(krp + 32 * 256 + pos);
       };
-      kread(0, 0);
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        if (kk < 7) kread(kk + 1, (kk + 1) & 1);   // the next fragments are on their way while these are multiplied
-        __builtin_amdgcn_sched_barrier(0);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk & 1][0], qf[kk], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk & 1][1], qf[kk], s1, 0, 0, 0);
-      }
-      if (qscale > 0.f) {                          // `bmm` under autocast returns fp16 scores
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = (float)(_Float16)s0[r]; s1[r] = (float)(_Float16)s1[r]; }
-      }
-      if (key0 + AT_KB > S) {                      // keys past the end of the sequence (last block only)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int k = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (k >= S) s0[r] = -1e30f;
-          if (k + 32 >= S) s1[r] = -1e30f;
-        }
-      }
-      // ---- online softmax over the 64 keys (base 2, scores scaled by c inside the exponent)
-      float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mn = fmaxf(m, mx);
-      if (__any(mn > m)) {                         // rescale what has been accumulated under the old maximum
-        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-        l *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        m = mn;
-      }
-      const float mc = m * c;
-      float rs = 0.f;
-      half8 pf[4];                                 // P fragments of the four k-steps (16 permuted keys each)
-      {
-        typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
-        unsigned pw[4][4];
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc)), a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
-          const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc)), b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
-          rs += (a0 + a1) + (b0 + b1);
-          const half2_ ha = {(_Float16)a0, (_Float16)a1}, hb = {(_Float16)b0, (_Float16)b1};   // one v_cvt_pk_f16_f32 each
-          pw[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(unsigned, ha);
-          pw[2 + (r >> 3)][(r & 7) >> 1] = __builtin_bit_cast(unsigned, hb);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const uint4_ w = {pw[t][0], pw[t][1], pw[t][2], pw[t][3]};
-          pf[t] = __builtin_bit_cast(half8, w);
-        }
-      }
-      rs += __shfl_xor(rs, 32);
-      l += rs;
-      // ---- O^T += V^T P^T: k-step outer, d tile inner (four independent accumulators in rotation); the fragments of
-      // the next k-step are requested before the MFMAs of this one
+      for (int kk = 0; kk < KRING - 1; ++kk) kread(kk, kk);
+      // the V^T fragments of the first k-step of the second product are requested ahead of the softmax
       const unsigned char* vr0[4];
       const unsigned char* vr1[4];
 #pragma unroll
@@ -239,7 +205,8 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
         vr0[dt] = vb + d * AT_VROW + (((4 * hi) ^ vswz(d)) << 1);
         vr1[dt] = vb + d * AT_VROW + (((8 + 4 * hi) ^ vswz(d)) << 1);
       }
-      half4 va[2][4], vc[2][4];
+      constexpr int VRING = 2;
+      half4 va[VRING][4], vc[VRING][4];
       auto vread = [&](int ks, int slot) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -247,16 +214,84 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
           vc[slot][dt] = *reinterpret_cast<const half4*>(vr1[dt] + 32 * ks);
         }
       };
-      vread(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk + KRING - 1 < 8) kread(kk + KRING - 1, (kk + KRING - 1) % KRING);
+        else if (kk + KRING - 1 - 8 < VRING - 1) vread(kk + KRING - 1 - 8, kk + KRING - 1 - 8);   // V^T k-steps 0 .. VRING-2
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          s[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk % KRING][0], qf[t][kk], s[t][0], 0, 0, 0);
+          s[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk % KRING][1], qf[t][kk], s[t][1], 0, 0, 0);
+        }
+      }
+      half8 pf[QT][4];                             // P fragments of the four k-steps (16 permuted keys each)
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        float16_& s0 = s[t][0];
+        float16_& s1 = s[t][1];
+        if (qscale > 0.f) {                        // `bmm` under autocast returns fp16 scores
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s0[r] = (float)(_Float16)s0[r]; s1[r] = (float)(_Float16)s1[r]; }
+        }
+        if (key0 + AT_KB > S) {                    // keys past the end of the sequence (last block only)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (k >= S) s0[r] = -1e30f;
+            if (k + 32 >= S) s1[r] = -1e30f;
+          }
+        }
+        // ---- online softmax over the 64 keys (base 2, scores scaled by c inside the exponent)
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m[t], mx);
+        if (__any(mn > m[t])) {                    // rescale what has been accumulated under the old maximum
+          const float alpha = __builtin_amdgcn_exp2f((m[t] - mn) * c);
+          l[t] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][dt][r] *= alpha;
+          m[t] = mn;
+        }
+        const float mc = m[t] * c;
+        float rs = 0.f;
+        {
+          typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+          unsigned pw[4][4];
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc)), a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
+            const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc)), b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
+            rs += (a0 + a1) + (b0 + b1);
+            const half2_ ha = {(_Float16)a0, (_Float16)a1}, hb = {(_Float16)b0, (_Float16)b1};   // one v_cvt_pk_f16_f32 each
+            pw[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(unsigned, ha);
+            pw[2 + (r >> 3)][(r & 7) >> 1] = __builtin_bit_cast(unsigned, hb);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint4_ w = {pw[u][0], pw[u][1], pw[u][2], pw[u][3]};
+            pf[t][u] = __builtin_bit_cast(half8, w);
+          }
+        }
+        rs += __shfl_xor(rs, 32);
+        l[t] += rs;
+      }
+      // ---- O^T += V^T P^T: k-step outer, query tile and d tile inner (4 QT independent accumulators in rotation); the
+      // fragments of the next VRING-1 k-steps are requested before the MFMAs of this one
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) vread(ks + 1, (ks + 1) & 1);
+        if (ks + VRING - 1 < 4) vread(ks + VRING - 1, (ks + VRING - 1) % VRING);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const half4 lo = va[ks & 1][dt], hi4 = vc[ks & 1][dt];
+          const half4 lo = va[ks % VRING][dt], hi4 = vc[ks % VRING][dt];
           const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ks], o[dt], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t][ks], o[t][dt], 0, 0, 0);
         }
       }
     }
@@ -265,25 +300,28 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
     __syncthreads();
   }
 
-  // ---- normalise, transpose through a wave-private LDS tile [32 queries][128 d] (16-byte chunks XORed with q & 15),
+  // ---- normalise, transpose through a wave-private LDS tile [32 QT queries][128 d] (16-byte chunks XORed with q & 15),
   // store whole 256-byte rows
-  unsigned char* tile = smem + wid * (32 * 256);   // 8 x 8 KiB inside the two buffers (everyone is past the last barrier)
+  unsigned char* tile = smem + wid * (32 * QT * 256);   // WAVES x 8 QT KiB = 64 KiB inside the two buffers (everyone is past the last barrier)
   if (wave_active) {
-    const float inv = 1.0f / l;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int t = 0; t < QT; ++t) {
+      const float inv = 1.0f / l[t];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        half4 v;
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(o[dt][4 * g + e] * inv);
-        const int chunk = (4 * dt + g) ^ (lq & 15);
-        *reinterpret_cast<half4*>(tile + lq * 256 + (chunk << 4) + 8 * hi) = v;
-      }
+        for (int g = 0; g < 4; ++g) {
+          half4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (_Float16)(o[t][dt][4 * g + e] * inv);
+          const int chunk = (4 * dt + g) ^ (lq & 15);
+          *reinterpret_cast<half4*>(tile + (32 * t + lq) * 256 + (chunk << 4) + 8 * hi) = v;
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the tile is wave-private, no barrier needed
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 8 * QT; ++it) {
       const int idx = lane + 64 * it;
       const int r = idx >> 4, ch = idx & 15;
       const int q = q0 + r;
@@ -295,7 +333,23 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_f16(const _Float16*
   }
 }
 
+template <int QT, int WAVES>
+int at_launch(const void* qkv, void* out, int B, int S, int H, float c, float qscale, hipStream_t stream) {
+  static_assert(WAVES * 32 * QT * 256 <= AT_LDS, "the output tiles reuse the K / V buffers");
+  const long long wgs = (long long)B * H * ((S + 32 * QT * WAVES - 1) / (32 * QT * WAVES));
+  FP_REQUIRE(wgs < (1ll << 31), "fp_attention_f16_fwd: too many workgroups");
+  FP_SET_MAX_LDS((k_attention_f16<QT, WAVES>), AT_LDS);
+  hipLaunchKernelGGL((k_attention_f16<QT, WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), AT_LDS, stream,
+                     (const _Float16*)qkv, (_Float16*)out, S, H, c, qscale);
+  FP_CHECK_LAUNCH("fp_attention_f16_fwd");
+  return FP_OK;
+}
+
 }  // namespace
+
+#ifndef AT_DEFAULT_QT
+#define AT_DEFAULT_QT 2
+#endif
 
 extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, int H, int head_dim, int flags, void* stream) {
   FP_REQUIRE(B >= 0 && S >= 0, "fp_attention_f16_fwd: negative size");
@@ -303,15 +357,17 @@ extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, in
   FP_REQUIRE(qkv && out, "fp_attention_f16_fwd: NULL tensor");
   FP_REQUIRE(head_dim == AT_D, "fp_attention_f16_fwd: head_dim=%d (only 128 is built)", head_dim);
   FP_REQUIRE(H > 0 && ((((size_t)qkv | (size_t)out) & 15) == 0), "fp_attention_f16_fwd: bad head count / unaligned tensors");
-  const long long wgs = (long long)B * H * ((S + 32 * AT_WAVES - 1) / (32 * AT_WAVES));
-  FP_REQUIRE(wgs < (1ll << 31), "fp_attention_f16_fwd: too many workgroups");
   FP_REQUIRE((flags & ~FP_ATT_FP16_SCORES) == 0, "fp_attention_f16_fwd: unknown flags 0x%x", flags);
-  FP_SET_MAX_LDS(k_attention_f16, AT_LDS);
   const bool f16s = (flags & FP_ATT_FP16_SCORES) != 0;
   const float qscale = f16s ? (float)sqrt(1.0 / (double)head_dim) : 0.f;
   const float c = f16s ? 1.4426950408889634f : 1.4426950408889634f / sqrtf((float)head_dim);
-  hipLaunchKernelGGL(k_attention_f16, dim3((unsigned)wgs), dim3(AT_THREADS), AT_LDS, (hipStream_t)stream,
-                     (const _Float16*)qkv, (_Float16*)out, S, H, c, qscale);
-  FP_CHECK_LAUNCH("fp_attention_f16_fwd");
-  return FP_OK;
+  int qt = AT_DEFAULT_QT;
+#ifdef FP_PROFILE_BUILD
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("FP_ATT_QT"); forced = e ? atoi(e) : 0; }   // profiling build only: 1 | 2
+  if (forced == 1 || forced == 2) qt = forced;
+#endif
+  // two query tiles per wave pay off once a wave has two tiles of real queries; short sequences keep the 8 x 32 shape
+  if (qt == 2 && S > 32) return at_launch<2, 4>(qkv, out, B, S, H, c, qscale, (hipStream_t)stream);
+  return at_launch<1, 8>(qkv, out, B, S, H, c, qscale, (hipStream_t)stream);
 }
