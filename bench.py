@@ -142,7 +142,11 @@ class ClockSampler:
         import glob
         import threading
         self.freq = self.power = None
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        cards = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq*_input")):
+            lab = self._read_str(f.replace("_input", "_label"))
+            if lab == "sclk" and self._read_str(os.path.join(os.path.dirname(f), "name")) == "amdgpu":
+                cards.append(f)            # one per GPU: the shader clock of an amdgpu device
         if cards:
             self.freq = cards[min(index, len(cards) - 1)]
             pw = os.path.join(os.path.dirname(self.freq), "power1_average")
@@ -150,6 +154,14 @@ class ClockSampler:
         self.period, self.f, self.p = period_s, [], []
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read_str(path):
+        try:
+            with open(path) as fh:
+                return fh.read().strip()
+        except Exception:
+            return None
 
     @staticmethod
     def _read(path):

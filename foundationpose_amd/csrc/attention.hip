@@ -280,6 +280,10 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
         rs += __shfl_xor(rs, 32);
         l[t] += rs;
       }
+      // V of the next block goes to LDS HERE (its global loads were requested at the top of the block, two products ago),
+      // so that the 16-bit transposing scatter -- LDS-write-bound -- runs under the MFMAs of the second product instead of
+      // after them, in front of the barrier, with the matrix pipe idle (round 3)
+      if (blk + 1 < nblk) vstore(cur ^ 1);
       // ---- O^T += V^T P^T: k-step outer, query tile and d tile inner (4 QT independent accumulators in rotation); the
       // fragments of the next VRING-1 k-steps are requested before the MFMAs of this one
 #pragma unroll
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
         }
       }
     }
-    if (blk + 1 < nblk) vstore(cur ^ 1);
+    if (!wave_active && blk + 1 < nblk) vstore(cur ^ 1);   // waves without queries only help staging
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K pieces of the next block have landed
     __syncthreads();
   }
@@ -348,7 +352,7 @@ int at_launch(const void* qkv, void* out, int B, int S, int H, float c, float qs
 }  // namespace
 
 #ifndef AT_DEFAULT_QT
-#define AT_DEFAULT_QT 2
+#define AT_DEFAULT_QT 1
 #endif
 
 extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, int H, int head_dim, int flags, void* stream) {
