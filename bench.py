@@ -149,8 +149,20 @@ class ClockSampler:
                 cards.append(f)            # one per GPU: the shader clock of an amdgpu device
         if cards:
             self.freq = cards[min(index, len(cards) - 1)]
-            pw = os.path.join(os.path.dirname(self.freq), "power1_average")
-            self.power = pw if os.path.exists(pw) else None
+            d = os.path.dirname(self.freq)
+            pw = [f for f in (os.path.join(d, "power1_average"), os.path.join(d, "power1_input")) if os.path.exists(f)]
+            self.power = pw[0] if pw else None
+            # one-shot readings next to the sampled shader clock: memory clock, junction temperature, power cap
+            self.static = {}
+            for f in sorted(glob.glob(os.path.join(d, "freq*_input"))):
+                lab = self._read_str(f.replace("_input", "_label"))
+                if lab and lab != "sclk":
+                    v = self._read(f)
+                    self.static[lab + "_MHz"] = None if v is None else v / 1e6
+            for name, f, scale in (("temp_junction_C", "temp2_input", 1e3), ("power_cap_W", "power1_cap", 1e6)):
+                v = self._read(os.path.join(d, f))
+                if v is not None:
+                    self.static[name] = v / scale
         self.period, self.f, self.p = period_s, [], []
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
@@ -199,6 +211,7 @@ class ClockSampler:
                "samples": len(self.f), "source": self.freq}
         if self.p:
             out["power_W_mean"] = statistics.fmean(self.p)
+        out.update(getattr(self, "static", {}))
         return out
 
 

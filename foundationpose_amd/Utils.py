@@ -154,6 +154,28 @@ def depth2xyzmap_batch(depths, Ks, zfar):
 
 
 # ------------------------------------------------------------------ small transforms
+def warp_perspective_nearest(src, M, dsize):
+    """kornia.geometry.transform.warp_perspective(src, M, dsize, mode='nearest', align_corners=False) for the ONE call
+    site family that is not on the hot path: the normal-map warps of `use_normal=True` (predict_pose_refine.py:75-76), whose
+    results the reference stores in BatchPoseData and never feeds to a network.  kornia 0.7.2 semantics [3P, SURVEY App.
+    B.2]: the homography is conjugated with the [0, size-1] -> [-1, 1] pixel normalisations of source and destination,
+    inverted, applied to a linspace(-1, 1) grid, and handed to F.grid_sample (zeros padding).  Plain torch ops on the
+    tensors' device.  src (B,C,H,W), M (B,3,3) source-pixel -> destination-pixel."""
+    import torch.nn.functional as F
+    B, _, H, W = src.shape
+    h, w = int(dsize[0]), int(dsize[1])
+
+    def norm_px(hh, ww):
+        return torch.tensor([[2.0 / (ww - 1), 0.0, -1.0], [0.0, 2.0 / (hh - 1), -1.0], [0.0, 0.0, 1.0]], dtype=M.dtype, device=M.device)
+    dst_from_src = norm_px(h, w)[None] @ (M @ torch.linalg.inv(norm_px(H, W))[None])
+    src_from_dst = torch.linalg.inv(dst_from_src)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, h, dtype=M.dtype, device=M.device),
+                            torch.linspace(-1, 1, w, dtype=M.dtype, device=M.device), indexing="ij")
+    grid = torch.stack([xs, ys, torch.ones_like(xs)], -1).reshape(1, -1, 3) @ src_from_dst.transpose(1, 2)
+    grid = (grid[..., :2] / grid[..., 2:3]).reshape(B, h, w, 2)
+    return F.grid_sample(src, grid.to(src.dtype), mode="nearest", padding_mode="zeros", align_corners=False)
+
+
 def to_homo_torch(pts):
     """(..., d) -> (..., d+1) with a trailing 1 (Utils.py:520-526)"""
     return torch.nn.functional.pad(pts.to(torch.float), (0, 1), value=1.0)

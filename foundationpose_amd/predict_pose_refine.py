@@ -70,10 +70,24 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
                          xyz_thr=0.001, normalize_xyz=normalize, A_out=AB[b:e])
         ops.warp_crops(rgb, xyz_map, None, tf_to_crops[b:e], K, poseA[b:e], mesh_diameter, ops.MODE_REFINE,
                        normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[N + b:N + e])
+    normalAs = normalBs = None
+    if cfg.get("use_normal", False):
+        # predict_pose_refine.py:50,58,75-76: the rendered normals and the frame's normal map go through the SAME nearest
+        # warp by tf_to_crops (the rendered crop is treated as if it were a frame -- reference behaviour, kept) into
+        # BatchPoseData.normalAs / normalBs.  The reference never concatenates them into the network input (:187-188 take rgb
+        # and xyz only), so this is bookkeeping off the hot path: plain torch ops, and refine_part() skips it.
+        if normal_map is None:
+            raise ValueError("use_normal=True needs a normal_map (the reference fails in torch.as_tensor(None) here)")
+        from .Utils import warp_perspective_nearest
+        nr = torch.cat([ops.render_crops(handle, poseA[b:b + 4096], bbox2d[b:b + 4096], K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
+                                         xyz_thr=0.001, normalize_xyz=normalize, want=("normal",))["normal"] for b in range(0, N, 4096)])
+        normalAs = warp_perspective_nearest(nr.permute(0, 3, 1, 2).contiguous(), tf_to_crops, render_size)
+        nm = torch.as_tensor(normal_map, dtype=torch.float, device=handle.device).permute(2, 0, 1)[None].expand(N, -1, -1, -1)
+        normalBs = warp_perspective_nearest(nm, tf_to_crops, render_size)
     Ks = torch.as_tensor(np.asarray(K, dtype=np.float64), device=handle.device, dtype=torch.float).reshape(1, 3, 3)
     mesh_diameters = torch.ones((N,), dtype=torch.float, device=handle.device) * float(mesh_diameter)
     batch = BatchPoseData(rgbAs=AB[:N, :3], rgbBs=AB[N:, :3], xyz_mapAs=AB[:N, 3:], xyz_mapBs=AB[N:, 3:], poseA=poseA,
-                          tf_to_crops=tf_to_crops, Ks=Ks, mesh_diameters=mesh_diameters)
+                          normalAs=normalAs, normalBs=normalBs, tf_to_crops=tf_to_crops, Ks=Ks, mesh_diameters=mesh_diameters)
     batch.AB = AB
     batch.bbox2d = bbox2d
     if dataset is not None:
@@ -106,10 +120,13 @@ class PoseRefinePredictor:
         for k in ("input_resize", "trans_normalizer", "rot_normalizer"):
             if k not in self.cfg:
                 raise KeyError(f"refiner cfg lacks required key '{k}'")
-        if self.cfg["use_normal"]:
-            raise NotImplementedError("use_normal=True is not supported (the released models use c_in=6)")
+        # use_normal=True is accepted: in the reference it only adds normalAs / normalBs to the BatchPoseData of
+        # make_crop_data_batch (above); predict() builds A and B from rgb and xyz alone (predict_pose_refine.py:187-188),
+        # so the networks -- and refine_part() here -- never see the normals.  For the same reason c_in has to be 6: with any
+        # other value the reference's own forward fails on the 6-channel A / B (channel mismatch in the first conv).
         if self.cfg["c_in"] != 6:
-            raise NotImplementedError("c_in must be 6 (rgb + xyz)")
+            raise NotImplementedError("c_in must be 6: predict() feeds cat([rgb, xyz]) to the network whatever use_normal says "
+                                      "(predict_pose_refine.py:187-188); the reference fails in its first conv otherwise")
         self.dataset = PoseRefinePairH5Dataset(cfg=self.cfg, h5_file="", mode="test")
         self.device = torch.device(device)
         self.precision = precision

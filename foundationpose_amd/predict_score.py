@@ -64,8 +64,10 @@ class ScorePredictor:
         for k, v in _SCORE_DEFAULTS.items():  # predict_score.py:131-142
             if k not in self.cfg or (k == "crop_ratio" and self.cfg[k] is None):
                 self.cfg[k] = v
-        if self.cfg["use_normal"] or self.cfg["c_in"] != 6:
-            raise NotImplementedError("only c_in=6 (rgb + xyz) without normals is implemented")
+        # use_normal=True only makes the reference render normals it then drops (predict_score.py:78,107-108: normalAs =
+        # normalBs = None); accepted and without effect here.  c_in has to be 6 for the same reason as in the refiner.
+        if self.cfg["c_in"] != 6:
+            raise NotImplementedError("c_in must be 6: the scorer is fed cat([rgb, xyz]) (predict_score.py:188-189)")
         self.dataset = ScoreMultiPairH5Dataset(cfg=self.cfg, mode="test", h5_file=None, max_num_key=1)
         self.device = torch.device(device)
         self.precision = precision

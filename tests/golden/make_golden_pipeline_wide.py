@@ -8,6 +8,9 @@ MORE of the hypothesis set than pipeline_golden.npz (3 poses, fp32 only):
              outputs, ScorePredictor.predict (amp off) scores
   pair_*   exactly two poses through the refiner's make_crop_data_batch: the N == 2 broadcasting quirk of
            predict_pose_refine.py:44-45 (both hypotheses rendered with [umin_0, vmin_0, umax_1, vmax_1])
+  un_*     use_normal=True through the refiner's make_crop_data_batch (3 poses): BatchPoseData.normalAs / normalBs -- the rendered
+           normals and a synthetic frame normal map, both through the nearest warp by tf_to_crops -- which the reference
+           stores and never feeds to the network
   amp_*    the first 8 of the 32 poses through both predictors with amp=True.  `torch.cuda.amp.autocast` needs a GPU; in
            the build container it is redirected to torch.autocast('cpu', dtype=float16): same cast policy for these
            modules except where the conv bias is added (CPU: fp32 accumulator; CUDA/ROCm: rounded fp16 output) -- see
@@ -42,6 +45,13 @@ def wide_poses(grid):
     P[5, :3, 3] += [0.0, 0.0, 0.35]        # farther: window smaller than 160 px (magnifying warp)
     P[12, :3, 3] += [0.01, -0.01, -0.3]    # nearer: window larger than the object crop (minifying warp)
     return P.astype(np.float32)
+
+
+def normal_map_for_tests(H=480, W=640):
+    """a seeded (H,W,3) unit-normal map of the frame (any smooth field will do: it is only resampled)"""
+    v, u = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    n = np.stack([np.sin(u * 0.031) * 0.6, np.cos(v * 0.043) * 0.5, -np.ones_like(u)], -1)
+    return (n / np.linalg.norm(n, axis=-1, keepdims=True)).astype(np.float32)
 
 
 def main():
@@ -85,6 +95,17 @@ def main():
     out["pair_poses_in"] = P2
     out["pair_refine_A"] = torch.cat([pd.rgbAs, pd.xyz_mapAs], 1).numpy()[:, :, ::2, ::2].astype(np.float32)
     out["pair_refine_B"] = torch.cat([pd.rgbBs, pd.xyz_mapBs], 1).numpy()[:, :, ::2, ::2].astype(np.float32)
+    # ---- use_normal=True (predict_pose_refine.py:50,58,75-76): normalAs / normalBs of the batch (never fed to the network)
+    ncfg = Cfg(dict(rcfg, use_normal=True))
+    nds = ns.h5_dataset.PoseRefinePairH5Dataset(cfg=ncfg, h5_file="", mode="test")
+    nm = normal_map_for_tests()
+    P3 = P[[0, 3, 12]].copy()
+    pd = ns.refine.make_crop_data_batch(ncfg.input_resize, torch.as_tensor(P3), mesh, rgb_t, depth_t, K, crop_ratio=ncfg["crop_ratio"],
+                                        xyz_map=xyz_t, normal_map=nm, cfg=ncfg, glctx=None, mesh_tensors=mt, dataset=nds, mesh_diameter=diam)
+    out["un_poses_in"] = P3
+    out["un_normalAs"] = pd.normalAs.numpy()[:, :, ::2, ::2].astype(np.float32)
+    out["un_normalBs"] = pd.normalBs.numpy()[:, :, ::2, ::2].astype(np.float32)
+    out["un_A"] = torch.cat([pd.rgbAs, pd.xyz_mapAs], 1).numpy()[:, :, ::4, ::4].astype(np.float32)   # unchanged by the flag
     # ---- predictors, fp32
     rsd, ssd = random_state_dict("refine", dict(rcfg), 0), random_state_dict("score", dict(scfg), 0)
 

@@ -454,6 +454,47 @@ def test_hip_network_inputs_and_predictors_match_wide_reference_golden(scene, de
     assert np.argmax(s) == np.argmax(g["w_scores"])
 
 
+def test_use_normal_true_is_the_reference_behaviour(scene, dev, gmesh, frame):
+    """cfg use_normal=True (predict_pose_refine.py:50,58,75-76; predict_score.py:78): make_crop_data_batch adds normalAs /
+    normalBs to the batch (golden minted by the reference's own function), predict() feeds the networks rgb + xyz only
+    (:187-188) -- so the refined poses and scores are bit-identical with and without the flag; c_in != 6 is refused (the
+    reference fails in its first conv)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_pipeline_wide import normal_map_for_tests
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor, make_crop_data_batch
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "pipeline_golden_wide.npz")))
+    cfg = dict(DEFAULT_REFINE_CFG, use_normal=True)
+    nm = normal_map_for_tests()
+    b = make_crop_data_batch(cfg["input_resize"], g["un_poses_in"], scene["mesh"], frame["rgb_t"], frame["depth_t"], scene["K"],
+                             cfg["crop_ratio"], frame["xyz_t"], normal_map=nm, mesh_diameter=scene["diameter"], cfg=cfg, mesh_tensors=gmesh)
+    nA, nB = b.normalAs.cpu().numpy()[:, :, ::2, ::2], b.normalBs.cpu().numpy()[:, :, ::2, ::2]
+    assert (np.abs(nB - g["un_normalBs"]) > 1e-6).any(1).mean() < 2e-3
+    assert (np.abs(nA - g["un_normalAs"]) > 2e-3).any(1).mean() < 5e-3
+    with pytest.raises(ValueError):
+        make_crop_data_batch(cfg["input_resize"], g["un_poses_in"], scene["mesh"], frame["rgb_t"], frame["depth_t"], scene["K"],
+                             cfg["crop_ratio"], frame["xyz_t"], normal_map=None, mesh_diameter=scene["diameter"], cfg=cfg, mesh_tensors=gmesh)
+    sd = random_state_dict("refine", dict(DEFAULT_REFINE_CFG), 0)
+    P = scene["poses"][:40]
+    outs = []
+    for c in (dict(DEFAULT_REFINE_CFG), cfg):
+        pred = PoseRefinePredictor(cfg=c, state_dict=sd, device=dev)
+        o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P, frame["xyz_t"], normal_map=nm, mesh=scene["mesh"],
+                            mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=2)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    scfg = dict(DEFAULT_SCORE_CFG, use_normal=True)
+    s0, _ = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", dict(DEFAULT_SCORE_CFG), 0), device=dev).predict(
+        scene["rgb"], frame["depth_t"], scene["K"], P, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    s1, _ = ScorePredictor(cfg=scfg, state_dict=random_state_dict("score", dict(DEFAULT_SCORE_CFG), 0), device=dev).predict(
+        scene["rgb"], frame["depth_t"], scene["K"], P, normal_map=nm, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    assert torch.equal(s0, s1)
+    with pytest.raises(NotImplementedError):
+        PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG, c_in=9), state_dict=sd, device=dev)
+
+
 # ------------------------------------------------------------------ hipGraph-captured tracking
 def test_graphed_tracker_replays_the_eager_result(scene, dev, gmesh, frame):
     """one captured graph per (frame size, N, iterations); replay == eager bit for bit, for changing inputs"""

@@ -124,3 +124,34 @@ def test_reference_predictors_one_pass_wide(scene, gold, frame, amp):
     if amp:   # the reference holds the raw outputs in fp16 under autocast
         assert np.array_equal(gold["amp_raw_trans"], gold["amp_raw_trans"].astype(np.float16).astype(np.float32))
         assert np.array_equal(tr[0]["trans"], tr[0]["trans"].astype(np.float16).astype(np.float32))
+
+
+def test_use_normal_batch_fields_match_reference(scene, gold, frame):
+    """use_normal=True (predict_pose_refine.py:50,58,75-76): normalBs = nearest warp of the frame's normal map, normalAs =
+    the SAME warp applied to the rendered normal crop (the reference treats the crop as a frame); the network inputs do not
+    change.  The product's kornia-semantics warp (Utils.warp_perspective_nearest, torch ops) on the oracle's crop windows
+    and rendered normals against what the reference's make_crop_data_batch returned."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(GOLD))
+    from make_golden_pipeline_wide import normal_map_for_tests
+    from foundationpose_amd.Utils import warp_perspective_nearest
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG
+    from oracle import ops as oo
+    from oracle import pipeline as op
+    cfg = dict(DEFAULT_REFINE_CFG)
+    P3 = gold["un_poses_in"]
+    tf, bb = oo.crop_windows(P3, scene["K"], scene["diameter"], cfg["crop_ratio"], (160, 160))
+    tf_t = torch.as_tensor(tf)
+    nm = torch.as_tensor(normal_map_for_tests()).permute(2, 0, 1)[None].expand(3, -1, -1, -1)
+    nB = warp_perspective_nearest(nm, tf_t, (160, 160)).numpy()[:, :, ::2, ::2]
+    bad = (np.abs(nB - gold["un_normalBs"]) > 1e-6).any(1)
+    assert bad.mean() < 2e-3, bad.mean()                        # nearest-neighbour ties on window edges only
+    assert np.abs(gold["un_normalBs"]).max() > 0.5 and (gold["un_normalBs"][1] == 0).all(0).mean() > 0.05   # pose 1 leaves the frame
+    nr = oo.render_crops(scene["mesh_np"], P3, bb, scene["K"], 480, 640, (160, 160), scene["diameter"], 0.001, True, want=("normal",))["normal"]
+    nA = warp_perspective_nearest(torch.as_tensor(nr).permute(0, 3, 1, 2).contiguous(), tf_t, (160, 160)).numpy()[:, :, ::2, ::2]
+    badA = (np.abs(nA - gold["un_normalAs"]) > 2e-3).any(1)
+    assert badA.mean() < 5e-3, badA.mean()
+    # the flag does not change the network input
+    A, _, _, _ = op.refine_inputs(cfg, P3, scene["mesh_np"], scene["rgb"], frame["xyz"], scene["K"], scene["diameter"])
+    check_A(A[:, :, ::4, ::4], gold["un_A"], max_edge_frac=4e-3)
