@@ -147,8 +147,20 @@ class ClockSampler:
             lab = self._read_str(f.replace("_input", "_label"))
             if lab == "sclk" and self._read_str(os.path.join(os.path.dirname(f), "name")) == "amdgpu":
                 cards.append(f)            # one per GPU: the shader clock of an amdgpu device
+        # the node's sysfs lists every GPU of the host, the process may see one of them: pick the card whose PCI address is
+        # the torch device's (falls back to the index-th card)
+        pick = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for f in cards:
+                if addr in os.path.realpath(f):
+                    pick = f
+        except Exception:
+            pick = None
+        self.matched_pci = pick is not None
         if cards:
-            self.freq = cards[min(index, len(cards) - 1)]
+            self.freq = pick or cards[min(index, len(cards) - 1)]
             d = os.path.dirname(self.freq)
             pw = [f for f in (os.path.join(d, "power1_average"), os.path.join(d, "power1_input")) if os.path.exists(f)]
             self.power = pw[0] if pw else None
@@ -208,7 +220,7 @@ class ClockSampler:
             return {"sclk_MHz_mean": None, "samples": 0, "source": self.freq}
         import statistics
         out = {"sclk_MHz_mean": statistics.fmean(self.f), "sclk_MHz_min": min(self.f), "sclk_MHz_max": max(self.f),
-               "samples": len(self.f), "source": self.freq}
+               "samples": len(self.f), "source": self.freq, "source_matches_torch_device_pci": bool(getattr(self, "matched_pci", False))}
         if self.p:
             out["power_W_mean"] = statistics.fmean(self.p)
         out.update(getattr(self, "static", {}))
