@@ -350,7 +350,13 @@ def main():
     # third pass, only when the step is split: the same kernels in ONE launch sequence over all hypotheses -- the launch
     # sizes of `--streams 1` and of rounds 1 / 2a, for a like-for-like per-launch figure of the dominant kernel
     timers_full = ops.KernelTimers()
-    if not args.no_kernel_table and len(refiner.sub.parts(N, dev)) > 1:
+    # whether the step is split is decided per process by a stream-overlap probe + an exactness canary (overlap.py); every
+    # extra pass below contains the step's collective, so under torch.distributed all ranks must take the same branch
+    split = torch.tensor([1 if len(refiner.sub.parts(N, dev)) > 1 else 0], device=dev, dtype=torch.int32)
+    if use_dist:
+        dist.all_reduce(split, op=dist.ReduceOp.MIN)
+    split = bool(split.item())
+    if not args.no_kernel_table and split:
         ns = refiner.sub.n_streams
         refiner.sub.n_streams = scorer.sub.n_streams = 1
         step()
@@ -363,7 +369,7 @@ def main():
     # fourth pass: the launches of the TIMED mode (sub-batches on concurrent streams) with HIP events on their own streams:
     # busy time of the dominant kernel = union of its launch intervals, i.e. its roofline in the execution mode that is timed
     timers_conc, conc_ref, conc_wall = ops.KernelTimers(), None, None
-    if not args.no_kernel_table and not args.serialize and len(refiner.sub.parts(N, dev)) > 1:
+    if not args.no_kernel_table and not args.serialize and split:
         step()
         sync()
         conc_ref = torch.cuda.Event(enable_timing=True)

@@ -37,7 +37,8 @@ def reserve_streams(device, k=1):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     side = _SIDE.setdefault(idx, [])
     while len(side) < k:
-        st = torch.cuda.Stream(device=device)
+        prio = os.environ.get("FP_AMD_SIDE_PRIORITY", "").strip()      # experiment knob: HIP priority of the side stream
+        st = torch.cuda.Stream(device=device, priority=int(prio)) if prio not in ("", "0") else torch.cuda.Stream(device=device)
         with torch.cuda.stream(st):                  # first use: the runtime binds a stream to its hardware queue lazily
             torch.zeros(1, device=device)
         side.append(st)
