@@ -465,6 +465,15 @@ def main():
                             "intervals).  Cross-check from a rocprofv3 --kernel-trace of the default command: "
                             "scripts/concurrent_roofline.py -> profiles/r03_concurrent_roofline.json",
                     "other_entry_points_busy_ms": {n: round(v["busy_ms"], 3) for n, v in cb.items() if n != dom}}
+            ck_ = out["clock"]
+            if bound == "mfma" and ck_.get("sclk_MHz_mean") and ck_.get("source_matches_torch_device_pci"):
+                # the chip does not hold its 2.4 GHz boost clock under this load (DVFS: MI355X_MICROARCH.md); the MFMA peak scales
+                # with the shader clock, so this is the fraction of what the matrix cores could do AT THE CLOCK THEY RAN AT
+                pk = peak * ck_["sclk_MHz_mean"] / 2400.0
+                out["roofline"]["at_sampled_clock"] = {"sclk_MHz": ck_["sclk_MHz_mean"], "peak": pk, "frac": ach / pk,
+                                                       "frac_concurrent": (out["roofline"]["concurrent"]["achieved"] / pk)
+                                                       if "concurrent" in out["roofline"] else None,
+                                                       "note": "peak x sclk / 2400 MHz; `frac` above stays against the datasheet peak"}
             out["stage_raster_crop"] = {"bytes_per_pass": stage_bytes, "ms_per_pass": r_ms + w_ms,
                                         "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,
                                         "frac_of_hbm_peak": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -7,7 +7,7 @@
  * (foundationpose_amd/) never does.
  *
  * PARITY STATUS: pinned against golden vectors minted by the reference's own Python for this path
- * (tests/golden/pipeline_golden.npz, tests/test_oracle_pipeline_golden.py).  Still "parity unpinned": the
+ * (tests/golden/pipeline_golden.npz, pipeline_golden_wide.npz; tests/test_oracle_pipeline_golden*.py).  Still "parity unpinned": the
  * internals of nvdiffrast (rasterize/interpolate/texture), kornia (warp_perspective) and pytorch3d, which are
  * absent from /root/reference and from this container and are restated from their published semantics
  * (SURVEY.md App. B); NVIDIA Warp's two depth kernels are restated from their in-tree source (Utils.py:304-395).

@@ -67,3 +67,14 @@ def test_mesh_diameter_matches_reference():
         np.random.seed(seed)
         got = compute_mesh_diameter(model_pts=pts, n_sample=n_sample)
         assert np.float64(got) == G[f"diam_{name}"], (name, got, G[f"diam_{name}"])
+
+
+@pytest.mark.parametrize("name,sym", [("identity", None), ("both", "sym_both"), ("cont_x", "sym_cont_x"), ("discrete", "sym_discrete")])
+def test_oracle_cluster_poses_matches_reference_grid(name, sym):
+    """the oracle's C restatement of mycpp.cluster_poses keeps exactly the poses the reference's make_rotation_grid kept"""
+    from oracle import ops as oo
+    S = np.eye(4)[None] if sym is None else G[sym]
+    full = G["grid_identity"].astype(np.float64)           # identity symmetry keeps all 252 poses, in generation order
+    assert full.shape == (252, 4, 4)
+    keep = oo.cluster_poses(30, 99999, full, S)
+    assert np.array_equal(full[keep].astype(np.float32), G[f"grid_{name}"])
