@@ -22,6 +22,7 @@
 //     fragment reads are conflict-free and the scatter is 2-way).
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "fp_common.h"
 
 namespace {
@@ -173,26 +174,31 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
   vstore(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int blk = 0; blk < nblk; ++blk) {
+  auto do_block = [&](int blk, auto half_c) {
     const int cur = blk & 1;
     if (blk + 1 < nblk) stage_next(blk + 1, cur ^ 1);   // in flight while this block is multiplied
     const unsigned char* kb = smem + cur * AT_BUF;
     const unsigned char* vb = kb + AT_K_BYTES;
-    if (wave_active) {
+    // HALF: only the first 32 keys of the block exist (last block of a sequence with S mod 64 in 1..32, e.g. S = 400):
+    // the second score tile, its half of the softmax and k-steps 2-3 of the second product are skipped instead of
+    // multiplied with masked zeros -- 1/14 of the kernel's arithmetic at S = 400 (round 3)
+    auto block_compute = [&]() {
+      constexpr bool HALF = decltype(half_c)::value;
+      constexpr int NKT = HALF ? 1 : 2;           // 32-key score tiles of this block
       const int key0 = blk * AT_KB;
       // ---- S^T tiles = K (2 x 32 keys) x Q^T (QT x 32 queries): 2 QT independent accumulator chains
       float16_ s[QT][2];
 #pragma unroll
       for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[t][0][r] = 0.f; s[t][1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { s[t][0][r] = 0.f; s[t][1][r] = HALF ? -1e30f : 0.f; }
       const unsigned char* krp = kb + lq * 256;    // rows lq and 32 + lq share (row & 15)
       constexpr int KRING = 3;                     // fragment ring: the reads of the next KRING-1 k-steps are in flight
       half8 kf[KRING][2];
       auto kread = [&](int kk, int slot) {
         const int pos = ((2 * kk + hi) ^ (lq & 15)) << 4;
         kf[slot][0] = *reinterpret_cast<const half8*>(krp + pos);
-        kf[slot][1] = *reinterpret_cast<const half8*>(krp + 32 * 256 + pos);
+        if (!HALF) kf[slot][1] = *reinterpret_cast<const half8*>(krp + 32 * 256 + pos);
       };
 #pragma unroll
       for (int kk = 0; kk < KRING - 1; ++kk) kread(kk, kk);
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           s[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk % KRING][0], qf[t][kk], s[t][0], 0, 0, 0);
-          s[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk % KRING][1], qf[t][kk], s[t][1], 0, 0, 0);
+          if (!HALF) s[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk % KRING][1], qf[t][kk], s[t][1], 0, 0, 0);
         }
       }
       half8 pf[QT][4];                             // P fragments of the four k-steps (16 permuted keys each)
@@ -232,20 +238,20 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
         float16_& s1 = s[t][1];
         if (qscale > 0.f) {                        // `bmm` under autocast returns fp16 scores
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { s0[r] = (float)(_Float16)s0[r]; s1[r] = (float)(_Float16)s1[r]; }
+          for (int r = 0; r < 16; ++r) { s0[r] = (float)(_Float16)s0[r]; if (!HALF) s1[r] = (float)(_Float16)s1[r]; }
         }
         if (key0 + AT_KB > S) {                    // keys past the end of the sequence (last block only)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int k = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (k >= S) s0[r] = -1e30f;
-            if (k + 32 >= S) s1[r] = -1e30f;
+            if (!HALF && k + 32 >= S) s1[r] = -1e30f;
           }
         }
         // ---- online softmax over the 64 keys (base 2, scores scaled by c inside the exponent)
-        float mx = fmaxf(s0[0], s1[0]);
+        float mx = HALF ? s0[0] : fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        for (int r = 1; r < 16; ++r) mx = HALF ? fmaxf(mx, s0[r]) : fmaxf(mx, fmaxf(s0[r], s1[r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mn = fmaxf(m[t], mx);
         if (__any(mn > m[t])) {                    // rescale what has been accumulated under the old maximum
@@ -265,11 +271,17 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc)), a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
-            const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc)), b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
-            rs += (a0 + a1) + (b0 + b1);
-            const half2_ ha = {(_Float16)a0, (_Float16)a1}, hb = {(_Float16)b0, (_Float16)b1};   // one v_cvt_pk_f16_f32 each
+            const half2_ ha = {(_Float16)a0, (_Float16)a1};   // one v_cvt_pk_f16_f32
             pw[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(unsigned, ha);
-            pw[2 + (r >> 3)][(r & 7) >> 1] = __builtin_bit_cast(unsigned, hb);
+            if constexpr (!HALF) {
+              const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc)), b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
+              rs += (a0 + a1) + (b0 + b1);
+              const half2_ hb = {(_Float16)b0, (_Float16)b1};
+              pw[2 + (r >> 3)][(r & 7) >> 1] = __builtin_bit_cast(unsigned, hb);
+            } else {
+              rs += (a0 + a1) + 0.f;        // the masked second tile contributes exp2(-inf) = 0: same sum, bit for bit
+              pw[2 + (r >> 3)][(r & 7) >> 1] = 0u;
+            }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -287,8 +299,8 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
       // ---- O^T += V^T P^T: k-step outer, query tile and d tile inner (4 QT independent accumulators in rotation); the
       // fragments of the next VRING-1 k-steps are requested before the MFMAs of this one
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks + VRING - 1 < 4) vread(ks + VRING - 1, (ks + VRING - 1) % VRING);
+      for (int ks = 0; ks < 2 * NKT; ++ks) {      // HALF: k-steps 2 and 3 would multiply V by zero probabilities
+        if (ks + VRING - 1 < 2 * NKT) vread(ks + VRING - 1, (ks + VRING - 1) % VRING);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -298,11 +310,17 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
           for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t][ks], o[t][dt], 0, 0, 0);
         }
       }
-    }
+    };
+    if (wave_active) block_compute();
     if (!wave_active && blk + 1 < nblk) vstore(cur ^ 1);   // waves without queries only help staging
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K pieces of the next block have landed
     __syncthreads();
-  }
+  };
+  // the main loop runs whole 64-key blocks; the last block is peeled so that its 32-key variant does not add to the
+  // register pressure of the loop (both variants inlined in the loop body cost 42 more VGPRs and spills)
+  for (int blk = 0; blk + 1 < nblk; ++blk) do_block(blk, std::false_type{});
+  if ((nblk - 1) * AT_KB + 32 >= S) do_block(nblk - 1, std::true_type{});
+  else do_block(nblk - 1, std::false_type{});
 
   // ---- normalise, transpose through a wave-private LDS tile [32 QT queries][128 d] (16-byte chunks XORed with q & 15),
   // store whole 256-byte rows
@@ -365,13 +383,11 @@ extern "C" int fp_attention_f16_fwd(const void* qkv, void* out, int B, int S, in
   const bool f16s = (flags & FP_ATT_FP16_SCORES) != 0;
   const float qscale = f16s ? (float)sqrt(1.0 / (double)head_dim) : 0.f;
   const float c = f16s ? 1.4426950408889634f : 1.4426950408889634f / sqrtf((float)head_dim);
-  int qt = AT_DEFAULT_QT;
 #ifdef FP_PROFILE_BUILD
+  // profiling build only: FP_ATT_QT=2 selects the measured-and-rejected 64-queries-per-wave shape
   static int forced = -1;
-  if (forced < 0) { const char* e = getenv("FP_ATT_QT"); forced = e ? atoi(e) : 0; }   // profiling build only: 1 | 2
-  if (forced == 1 || forced == 2) qt = forced;
+  if (forced < 0) { const char* e = getenv("FP_ATT_QT"); forced = e ? atoi(e) : 0; }
+  if ((forced == 2 || (forced == 0 && AT_DEFAULT_QT == 2)) && S > 32) return at_launch<2, 4>(qkv, out, B, S, H, c, qscale, (hipStream_t)stream);
 #endif
-  // two query tiles per wave pay off once a wave has two tiles of real queries; short sequences keep the 8 x 32 shape
-  if (qt == 2 && S > 32) return at_launch<2, 4>(qkv, out, B, S, H, c, qscale, (hipStream_t)stream);
   return at_launch<1, 8>(qkv, out, B, S, H, c, qscale, (hipStream_t)stream);
 }
