@@ -158,7 +158,16 @@ __device__ __forceinline__ void tri_weights(const TriSetup& t, int px, int py, i
 }
 
 __device__ __forceinline__ float lerpf(float a, float b, float c) { return fmaf(c, b - a, a); }
-__device__ __forceinline__ int wrapi(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
+// i mod n into [0, n).  The texel indices of tex_fetch are floor(u * n - 0.5) and that + 1 with u in [0, 1], i.e. -1 .. n: one
+// conditional add / subtract covers them; the emulated integer modulo (~35 VALU instructions, four per shaded pixel: a third
+// of the resolve phase's instructions, profiles/r03_stage_counters_sq.json) is only taken for anything further out.
+__device__ __forceinline__ int wrapi(int i, int n) {
+  if ((unsigned)i < (unsigned)n) return i;
+  if (i >= -n && i < 0) return i + n;
+  if (i >= n && i < 2 * n) return i - n;
+  int r = i % n;
+  return r < 0 ? r + n : r;
+}
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
 __device__ __forceinline__ void tex_fetch(const float* __restrict__ tex, int Ht, int Wt, float u, float v,
@@ -335,8 +344,12 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
     } else {                    // the lanes of a wave stride the cells of the box
       const int bw = i1 - i0 + 1;
       const int cells = bw * (j1 - j0 + 1);
-      for (int c = first; c < cells; c += step) {
-        const int jj = c / bw, i = i0 + (c - jj * bw), j = j0 + jj;
+      // cell (jj, ii) of c = first + k * step without a division per cell
+      const int sj = step / bw, si = step - sj * bw;
+      int jj = first / bw, ii = first - jj * bw;
+      for (int c = first; c < cells; c += step, ii += si, jj += sj) {
+        if (ii >= bw) { ii -= bw; ++jj; }
+        const int i = i0 + ii, j = j0 + jj;
         int w0, w1, w2;
         tri_weights(tr, 16 * i + 8, 16 * j + 8, w0, w1, w2);
         cell(i, j, w0, w1, w2);
@@ -397,8 +410,12 @@ __global__ __launch_bounds__(FP_RASTER_THREADS) void k_raster(
   const float t0 = h.P[3], t1 = h.P[7], t2 = h.P[11];
   const bool normalize = (flags & FP_FLAG_NORMALIZE_XYZ) != 0;
   const bool out_f16 = (flags & FP_FLAG_OUT_F16) != 0;
-  for (int p = tid; p < npix; p += FP_RASTER_THREADS) {
-    const int jl = p / ow, i = p - jl * ow, j = row0 + jl;
+  // pixel (jl, i) of p = tid + k * THREADS without a division per iteration
+  const int step_j = FP_RASTER_THREADS / ow, step_i = FP_RASTER_THREADS - step_j * ow;
+  int jl = tid / ow, i = tid - jl * ow;
+  for (int p = tid; p < npix; p += FP_RASTER_THREADS, i += step_i, jl += step_j) {
+    if (i >= ow) { i -= ow; ++jl; }
+    const int j = row0 + jl;
     const unsigned long long key = zb[p];
     const bool covered = key != FP_KEY_EMPTY;
     float col[3] = {0.f, 0.f, 0.f}, pt[3] = {0.f, 0.f, 0.f}, nm[3] = {0.f, 0.f, 0.f};

@@ -95,21 +95,37 @@ __device__ __forceinline__ void warp_pixel(const float* __restrict__ rgb, const 
 // MI355X: giving a lane 8 pixels (16-byte stores) is 4x SLOWER (0.34 ms vs 0.08 ms at N=252) -- the kernel is bound by
 // the gather of the 12-byte AoS frame texels through the vector L1 (about 23 cache lines per wave-load), not by its
 // stores, and fewer, fatter lanes only remove the parallelism that hides that latency.
+// Per-hypothesis constants of the warp (the inverse of the scale + translate crop transform): four IEEE divisions that
+// every lane of a workgroup used to repeat (~45 of its 319 VALU instructions per wave, profiles/r03_stage_counters_sq.json:
+// the kernel is VALU-issue-bound, 57 % of its wave cycles are issue stalls); now one lane computes them -- the same
+// instructions, so the same bits -- and the workgroup reads them from LDS.  The frame constants W/(W-1), H/(H-1) and the
+// row / column of a pixel (an emulated integer division) come from the host: float division there is the same IEEE
+// operation, the integer division a multiply-shift.
+struct WarpConst { float cW, cH; unsigned mul_ow, shr_ow; };
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_warp(const float* __restrict__ rgb, const float* __restrict__ xyz_map,
                                               const float* __restrict__ depthf, const float* __restrict__ tfs,
                                               fp_k9 K, const float* __restrict__ poses, float inv_r, int flags,
-                                              int H, int W, int oh, int ow, void* __restrict__ Bout) {
+                                              int H, int W, int oh, int ow, void* __restrict__ Bout, WarpConst wc) {
+  __shared__ float inv_tf[4];
   const int n = blockIdx.y;
+  const float* tf = tfs + (size_t)n * 9;
+  const float sx = tf[0], tx = tf[2], sy = tf[4], ty = tf[5];
+  if (threadIdx.x == 0) {
+    inv_tf[0] = 1.0f / sx;
+    inv_tf[1] = 1.0f / sy;
+    inv_tf[2] = (-tx) / sx;
+    inv_tf[3] = (-ty) / sy;
+  }
+  __syncthreads();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int npx = oh * ow;
   if (p >= npx) return;
-  const int j = p / ow, i = p - j * ow;
-  const float* tf = tfs + (size_t)n * 9;
-  const float sx = tf[0], tx = tf[2], sy = tf[4], ty = tf[5];
-  const float i00 = 1.0f / sx, i11 = 1.0f / sy;
-  const float i02 = (-tx) / sx, i12 = (-ty) / sy;
-  const float cW = (float)W / (float)(W - 1), cH = (float)H / (float)(H - 1);
+  const int j = wc.mul_ow ? (int)(__umulhi((unsigned)p, wc.mul_ow) >> wc.shr_ow) : p;
+  const int i = p - j * ow;
+  const float i00 = inv_tf[0], i11 = inv_tf[1], i02 = inv_tf[2], i12 = inv_tf[3];
+  const float cW = wc.cW, cH = wc.cH;
   const float* P = poses + (size_t)n * 16;
   float a[6];
   warp_pixel<MODE>(rgb, xyz_map, depthf, sx, tx, sy, ty, i00, i02, i11, i12, cW, cH, K, P[3], P[7], P[11], inv_r,
@@ -141,12 +157,25 @@ extern "C" int fp_warp_crops(const float* rgb, const float* xyz_map, const float
   for (int i = 0; i < 9; ++i) K.v[i] = K9[i];
   const float inv_r = 1.0f / (mesh_diameter * 0.5f);
   dim3 grid(fp_cdiv(oh * ow, 256), N), block(256);
+  WarpConst wc;
+  wc.cW = (float)W / (float)(W - 1);
+  wc.cH = (float)H / (float)(H - 1);
+  {   // p / ow for p < oh * ow <= 2^20 as umulhi(p, mul) >> shr (exact: ceil(2^(31+lg) / ow) with lg = ceil(log2 ow)); 0 = divisor 1
+    wc.mul_ow = 0; wc.shr_ow = 0;
+    if (ow > 1) {
+      int lg = 0;
+      while ((1u << lg) < (unsigned)ow) ++lg;
+      const int sh = 31 + lg;
+      wc.mul_ow = (unsigned)(((1ull << sh) + (unsigned)ow - 1) / (unsigned)ow);
+      wc.shr_ow = (unsigned)(sh - 32);
+    }
+  }
   if (mode == FP_MODE_REFINE)
     hipLaunchKernelGGL(k_warp<FP_MODE_REFINE>, grid, block, 0, (hipStream_t)stream, rgb, xyz_map, depth, tf_to_crops,
-                       K, poses, inv_r, flags, H, W, oh, ow, B);
+                       K, poses, inv_r, flags, H, W, oh, ow, B, wc);
   else
     hipLaunchKernelGGL(k_warp<FP_MODE_SCORE>, grid, block, 0, (hipStream_t)stream, rgb, xyz_map, depth, tf_to_crops,
-                       K, poses, inv_r, flags, H, W, oh, ow, B);
+                       K, poses, inv_r, flags, H, W, oh, ow, B, wc);
   FP_CHECK_LAUNCH("fp_warp_crops");
   return FP_OK;
 }
