@@ -50,6 +50,41 @@ __device__ __forceinline__ void ln_row(float eps, float f[8]) {
   for (int e = 0; e < 8; ++e) f[e] *= rstd;
 }
 
+// the same for R independent rows held by one wave, the R reduction chains interleaved (per row: exactly ln_row)
+template <int R>
+__device__ __forceinline__ void ln_rows(float eps, float f[R][8]) {
+  float s[R], q[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    s[u] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[u] += f[u][e];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) s[u] += __shfl_xor(s[u], o, 64);
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const float mean = s[u] * (1.0f / 512.0f);
+    q[u] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[u][e] -= mean; q[u] = fmaf(f[u][e], f[u][e], q[u]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) q[u] += __shfl_xor(q[u], o, 64);
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const float rstd = rsqrtf(q[u] * (1.0f / 512.0f) + eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[u][e] *= rstd;
+  }
+}
+
 // residual-stream value of row `row`, elements [8 lane, 8 lane + 8): x32 if given, else fp32(tok16) + pe[row % S]
 __device__ __forceinline__ void resid_row(const float* x32, const _Float16* tok16, const float* pe, int S, size_t row, int lane,
                                           float f[8]) {
@@ -109,22 +144,38 @@ __global__ __launch_bounds__(1024) void k_colmean512(const _Float16* __restrict_
   const int g = blockIdx.x;
   const size_t base = (size_t)g * rows_per_group * 512;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = wid; r < rows_per_group; r += 16) {
-    const half8 x = *reinterpret_cast<const half8*>(X + base + (size_t)r * 512 + lane * 8);
-    float f[8];
+  // A wave's rows (wid, wid + 16, ...) are taken CM_ROWS at a time: their loads go out together and their LayerNorm
+  // reductions -- twelve dependent cross-lane exchanges per row -- are interleaved; each row's arithmetic and the order in
+  // which rows enter `acc` are unchanged.  With one row in flight per wave the kernel ran at the latency of a load plus that
+  // chain (16 waves x 3 KB per CU and round trip: 3.1 TB/s on the 126 CUs a sub-batch's 126 groups occupy).
+  constexpr int CM_ROWS = 4;
+  for (int r0 = wid; r0 < rows_per_group; r0 += 16 * CM_ROWS) {
+    float f[CM_ROWS][8];
+    {
+      half8 x[CM_ROWS];
+      float rr[CM_ROWS][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (float)x[e];
-    if (LN) {
-      if (R32) {
-        float rr[8];
-        load8f(R32 + base + (size_t)r * 512 + lane * 8, rr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+      for (int u = 0; u < CM_ROWS; ++u) {
+        const int r = min(r0 + 16 * u, rows_per_group - 1);   // past the end: a valid row, normalised but never added
+        x[u] = *reinterpret_cast<const half8*>(X + base + (size_t)r * 512 + lane * 8);
+        if (LN && R32) load8f(R32 + base + (size_t)r * 512 + lane * 8, rr[u]);
       }
-      ln_row(eps, f);
-    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+      for (int u = 0; u < CM_ROWS; ++u) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f[u][e] = (float)x[u][e];
+          if (LN && R32) f[u][e] += rr[u][e];
+        }
+      }
+    }
+    if (LN) ln_rows<CM_ROWS>(eps, f);
+#pragma unroll
+    for (int u = 0; u < CM_ROWS; ++u) {
+      const bool live = r0 + 16 * u < rows_per_group;   // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = live ? acc[e] + f[u][e] : acc[e];
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) part[wid][lane * 8 + e] = acc[e];
