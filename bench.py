@@ -37,6 +37,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
 REFINE_GFLOP_PER_HYP = 23.946
 SCORE_GFLOP_PER_HYP = 21.938
 SCORE_GFLOP_CROSS_252 = 0.659
+STEM_GFLOP_PER_IMAGE = (80 * 80 * 64 * 6 * 49 + 40 * 40 * 128 * 64 * 9 + 4 * 40 * 40 * 128 * 128 * 9) * 2 / 1e9   # encodeA, one 160x160 image
 # roofline that bounds each hand-written kernel (DESIGN.md "Kernels")
 KERNEL_BOUND = {"fp_render_crops": "hbm", "fp_warp_crops": "hbm", "fp_conv7x7s2_bn_relu_fwd": "hbm",
                 "fp_igemm_f16_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
@@ -243,6 +244,10 @@ def main():
                     "(the launches of the per-kernel table; used for the rocprofv3 profile that table is checked against)")
     ap.add_argument("--trace-markers", action="store_true", help="bracket the timed region with two marker launches (k_depth_to_xyz on a "
                     "1 x 7 image) so that scripts/concurrent_roofline.py can cut it out of a rocprofv3 --kernel-trace of this command")
+    ap.add_argument("--shared-crop", action="store_true", help="tell the refiner that all hypotheses start at one translation, as "
+                    "estimater.register() does: the observed crop of the first iteration is then warped and stem-encoded once per "
+                    "sub-batch instead of once per hypothesis (bit-identical result).  Off by default: the headline runs every "
+                    "hypothesis's full arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (instrumented) pass")
     args = ap.parse_args()
@@ -293,10 +298,11 @@ def main():
     def step():
         if hyp_mode:
             p, s, _ = register_hypothesis_parallel(refiner, scorer, rgb_t, depth_t, sc["K"], poses0, xyz_t, mesh=sc["mesh"],
-                                                   mesh_tensors=sc["gm"], mesh_diameter=sc["diameter"], iteration=R)
+                                                   mesh_tensors=sc["gm"], mesh_diameter=sc["diameter"], iteration=R,
+                                                   shared_translation=args.shared_crop)
             return torch.cat([s.reshape(-1, 1), p.reshape(-1, 16)], dim=1)[None]   # replicated on every rank
         p, _ = refiner.predict(rgb_t, depth_t, sc["K"], poses0, xyz_t, mesh=sc["mesh"], mesh_tensors=sc["gm"],
-                               mesh_diameter=sc["diameter"], iteration=R)
+                               mesh_diameter=sc["diameter"], iteration=R, shared_translation=args.shared_crop)
         s, _ = scorer.predict(rgb_t, depth_t, sc["K"], p, mesh=sc["mesh"], mesh_tensors=sc["gm"],
                               mesh_diameter=sc["diameter"])
         ids = s.argsort(descending=True)
@@ -386,6 +392,10 @@ def main():
     if rank == 0:
         V, T = sc["gm"]["_handle"].V, sc["gm"]["_handle"].T
         flops = total_hyps * (R * REFINE_GFLOP_PER_HYP + SCORE_GFLOP_PER_HYP) + (1 if hyp_mode else world) * SCORE_GFLOP_CROSS_252 * (N / 252.0) ** 2
+        if args.shared_crop and args.precision == "fp16" and R > 0:
+            # arithmetic NOT executed with --shared-crop: the stem (patch-embed + 5 convs) of all but one observed crop per part
+            per_rank = (N + world - 1) // world if hyp_mode else N
+            flops -= world * max(0, per_rank - max(1, args.streams)) * STEM_GFLOP_PER_IMAGE
         out = {
             "metric": "pose-hypotheses/sec (raster+refine+score), 252 hyp x 160x160 @ 640x480 RGB-D",
             "value": total_hyps * args.steps / dt, "unit": "pose-hypotheses/sec", "n_gpus": world, "steps": args.steps,
@@ -395,6 +405,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: synthetic can (V={V}, T={T}), one 640x480 RGB-D frame per rank, "
                                    f"{N} hypotheses, {R} refine iterations + 1 score pass, 160x160 crops, random-init weights",
                        "hypotheses_per_gpu": (N + world - 1) // world if hyp_mode else N, "refine_iterations": R,
+                       "shared_observed_crop_in_iteration_0": bool(args.shared_crop and args.precision == "fp16"),
                        "network": {"fp16": "libfp_amd.so (hand-written MFMA kernels)", "torch_amp": "PyTorch-ROCm under torch.autocast "
                                    "(MIOpen / rocBLAS / ATen)", "fp32": "PyTorch-ROCm fp32"}[args.precision],
                        "parallelism": ("single GPU, no collective (torch.distributed not initialised)" if not use_dist else

@@ -84,16 +84,18 @@ class FeaturePoseExchange:
 
 
 def register_hypothesis_parallel(refiner, scorer, rgb, depth, K, poses_all, xyz_map, mesh=None, mesh_tensors=None,
-                                 mesh_diameter=None, iteration=5, group=None, collective=None, world_rank=None):
+                                 mesh_diameter=None, iteration=5, group=None, collective=None, world_rank=None,
+                                 shared_translation=None):
     """estimater.py:214-229 (refine all hypotheses, score them, sort) with the hypotheses sharded over the ranks.
     ``poses_all`` (N,4,4) is the same on every rank.  Returns (poses sorted by score (N,4,4), scores sorted (N,),
-    order) -- replicated on every rank.  collective / world_rank: see all_gather_rows."""
+    order) -- replicated on every rank.  collective / world_rank: see all_gather_rows; shared_translation: see
+    PoseRefinePredictor.predict."""
     world, rank = world_rank if world_rank is not None else _world(group)
     poses_all = torch.as_tensor(poses_all)
     N = poses_all.shape[0]
     b, e = shard_bounds(N, world)[rank]
     local, _ = refiner.predict(rgb, depth, K, poses_all[b:e], xyz_map, mesh=mesh, mesh_tensors=mesh_tensors,
-                               mesh_diameter=mesh_diameter, iteration=iteration)
+                               mesh_diameter=mesh_diameter, iteration=iteration, shared_translation=shared_translation)
     ex = FeaturePoseExchange(local, N, group, collective, world_rank)
     scores, _ = scorer.predict(rgb, depth, K, local, mesh=mesh, mesh_tensors=mesh_tensors,
                                mesh_diameter=mesh_diameter, feature_exchange=ex)

@@ -216,15 +216,19 @@ class _HipEncoder:
         return ops.igemm_f16(x, gin, c["w"], c["bias"], y, gout, Bn * Ho * Wo, Cout, Cin, 9, relu=relu, residual=res, r_geom=gres,
                              bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True, pe=pe, y_pe=y_pe)
 
-    def __call__(self, AB, slot=0):
+    def __call__(self, AB, slot=0, shared_b=False):
         """AB (2n,6,H,W) fp16 -> (tokens (n, H/8 * W/8, 512) fp16 before the positional table,
-        x16 = f16(f32(tokens) + pe): the in_proj operand, written by the same epilogue)"""
+        x16 = f16(f32(tokens) + pe): the in_proj operand, written by the same epilogue).
+        shared_b: AB is (n+1,6,H,W) -- n rendered crops and ONE observed crop that all n pairs share (the first refine
+        iteration of register(): every hypothesis has the same translation, hence the same crop window).  The shared stem
+        then runs on n+1 images instead of 2n and the B half of the concat is replicated; per element the same kernels in
+        the same order, so the result is bit-identical to feeding n copies."""
         n2, _, H, W = AB.shape
-        n = n2 // 2
+        n = n2 - 1 if shared_b else n2 // 2
         b = self._buffers(n, H, W, slot)
         h1, w1, h2, w2, h3, w3 = b["dims"]
         G = ops.IgemmGeom.image
-        ops.conv7x7s2_bn_relu(AB, self.c1_w, self.c1_b, self.c1_scale, self.c1_shift, b["P1"], 1)
+        ops.conv7x7s2_bn_relu(AB, self.c1_w, self.c1_b, self.c1_scale, self.c1_shift, b["P1"][:n2], 1)
         self._conv("c2", b["P1"], n2, h2, w2, 64, 128, b["P2"], stride=2)
         self._conv("s2a", b["P2"], n2, h2, w2, 128, 128, b["T"])
         self._conv("s2b", b["T"], n2, h2, w2, 128, 128, b["P3"], res=b["P2"])
@@ -232,6 +236,8 @@ class _HipEncoder:
         # stem output of image i (A) and image n+i (B) side by side along C: torch.cat((a, b), 1)
         self._conv("s3b", b["T"], n2, h2, w2, 128, 128, b["CAT"], res=b["P3"],
                    gout=G(h2, w2, 1, 256, bsplit=n, cgroup=128), gres=G(h2, w2, 1, 128))
+        if shared_b and n > 1:
+            b["CAT"][1:n, :, :, 128:].copy_(b["CAT"][0:1, :, :, 128:].expand(n - 1, -1, -1, -1))
         self._conv("j0a", b["CAT"], n, h2, w2, 256, 256, b["T2"])
         self._conv("j0b", b["T2"], n, h2, w2, 256, 256, b["J0"], res=b["CAT"])
         self._conv("j1a", b["J0"], n, h2, w2, 256, 256, b["T2"])
@@ -343,17 +349,20 @@ class RefinePlan:
                                     sd[f"{name}_head.1.weight"].to(self.dtype), sd[f"{name}_head.1.bias"].to(self.dtype))
 
     @torch.inference_mode()
-    def __call__(self, AB, slot=0):
+    def __call__(self, AB, slot=0, shared_b=False):
         """AB (2N,6,H,W) in the plan's dtype -> {'trans': (N,3) f32, 'rot': (N,3|6) f32}.  slot: activation-buffer set
-        (callers that overlap on different streams use different slots)"""
+        (callers that overlap on different streams use different slots).  shared_b (fp16 plan only): AB is (N+1,6,H,W),
+        the last image being the observed crop every pair shares (_HipEncoder.__call__)"""
         out = {}
+        if shared_b and not self.hip:
+            raise ValueError("shared_b is a property of the fp16 plan; expand the observed crop for the torch plans")
         if self.module is not None:
             n = AB.shape[0] // 2
             with _conv_backend(), torch.autocast("cuda", dtype=torch.float16):          # predict_pose_refine.py:190-191
                 o = self.module(AB[:n], AB[n:])
             return {k: v.float() for k, v in o.items()}                 # predict_pose_refine.py:192-193
         if self.hip:
-            tok16, x16 = self.enc(AB, slot)
+            tok16, x16 = self.enc(AB, slot, shared_b=shared_b)
             for name, (layer, head) in self.heads.items():
                 # Linear and the token mean commute: mean_t(x_t W^T + b) = (mean_t x_t) W^T + b, so the 512 -> 3|6 head
                 # runs on N rows instead of N*400 (refine_network.py:90-91); the result is held in fp16 by the reference

@@ -165,7 +165,8 @@ class FoundationPose:
         xyz_map = ops.depth_to_xyz(depth_t, K, zfar=float("inf"), f64_internal=True)  # depth2xyzmap (numpy variant)
         poses, vis = self.refiner.predict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth_t, K=K,
                                           ob_in_cams=poses, normal_map=None, xyz_map=xyz_map, glctx=self.glctx,
-                                          mesh_diameter=self.diameter, iteration=iteration, get_vis=self.debug >= 2)
+                                          mesh_diameter=self.diameter, iteration=iteration, get_vis=self.debug >= 2,
+                                          shared_translation=True)   # generate_random_pose_hypo: one centre for the whole grid
         scores, vis = self.scorer.predict(mesh=self.mesh, rgb=rgb, depth=depth_t, K=K, ob_in_cams=poses,
                                           normal_map=None, mesh_tensors=self.mesh_tensors, glctx=self.glctx,
                                           mesh_diameter=self.diameter, get_vis=self.debug >= 2)

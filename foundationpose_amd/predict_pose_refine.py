@@ -152,12 +152,15 @@ class PoseRefinePredictor:
         return oh, ow, tn, bool(self.cfg["normalize_xyz"])
 
     def refine_part(self, slot, rows, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iterations, outs, workspace=None,
-                    state=None):
+                    state=None, shared_translation=False):
         """Iterations `iterations` (a range) of the refine loop for the hypotheses rows=(a, b) of `poses`, on the CURRENT
         stream, with the activation-buffer set `slot`: per iteration fp_crop_windows -> fp_render_crops (A) +
         fp_warp_crops (B) -> RefineNet plan -> fp_pose_update.  outs = (poses_out (N,4,4), trans_delta (N,3), rot_delta
         (N,3,3), n_iterations_total): the last iteration writes rows a..b of them.  state: what the previous call for this
-        part returned (None for the first iteration).  -> state"""
+        part returned (None for the first iteration).  shared_translation: the hypotheses a..b of `poses` all have the same
+        translation (register(): estimater.py:132-133 puts every rotation of the grid at the guessed centre), so in
+        iteration 0 they share one crop window and one observed crop: it is warped once and the stem of the fp16 plan
+        encodes it once (engine._HipEncoder, bit-identical to 252 copies).  -> state"""
         plan = self.plan()
         a, b = rows
         n = b - a
@@ -175,9 +178,10 @@ class PoseRefinePredictor:
                 bbox2d = torch.stack([bbox2d[0, 0], bbox2d[0, 1], bbox2d[1, 2], bbox2d[1, 3]])[None].expand(2, 4).contiguous()
             ops.render_crops(mesh_handle, P, bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter, xyz_thr=0.001,
                              normalize_xyz=normalize, A_out=AB[:n], workspace=workspace)
-            ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops, K, P, mesh_diameter, ops.MODE_REFINE, normalize_xyz=normalize,
-                           out_hw=(oh, ow), B_out=AB[n:])
-            raw = plan(AB, slot=slot)
+            shared = bool(shared_translation) and it == 0 and n > 1 and plan.hip
+            ops.warp_crops(rgb_t, xyz_t, None, tf_to_crops[:1] if shared else tf_to_crops, K, P[:1] if shared else P, mesh_diameter,
+                           ops.MODE_REFINE, normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[n:n + 1] if shared else AB[n:])
+            raw = plan(AB[:n + 1], slot=slot, shared_b=True) if shared else plan(AB, slot=slot)
             state["raw"] = raw
             state["P"] = ops.pose_update(raw["trans"], raw["rot"], P, rot_rep=self.cfg["rot_rep"], normalize_xyz=normalize,
                                          trans_normalizer=tn, rot_normalizer=float(self.cfg["rot_normalizer"]),
@@ -187,7 +191,8 @@ class PoseRefinePredictor:
                                          tf_to_crops=tf_to_crops, input_w=float(self.cfg["input_resize"][0]))
         return state
 
-    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, workspace=None):
+    def refine_device(self, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, iteration, workspace=None,
+                      shared_translation=False):
         """The refine loop on device tensors only (predict_pose_refine.py:182-235).  No host round trip, no host-side
         tensor creation.  Hypotheses are independent through all iterations, so the parts of `self.sub.parts(N)` run the
         whole loop as independent launch sequences on concurrent streams (overlap.py), issued iteration by iteration and
@@ -214,7 +219,8 @@ class PoseRefinePredictor:
             for h, rows in enumerate(parts):
                 with torch.cuda.stream(streams[h]):
                     state[h] = self.refine_part(h, rows, rgb_t, xyz_t, poses, K, H, W, mesh_handle, mesh_diameter, range(it, it + 1),
-                                                outs, None if workspace is None else workspace[h], state[h])
+                                                outs, None if workspace is None else workspace[h], state[h],
+                                                shared_translation=shared_translation)
         self.sub.join(streams)
         self._raw_parts = [None if st is None else st["raw"] for st in state]   # last_raw_output
         return outs[:3]
@@ -233,10 +239,21 @@ class PoseRefinePredictor:
 
     @torch.inference_mode()
     def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None,
-                mesh_tensors=None, glctx=None, mesh_diameter=None, iteration=5):
-        """@rgb (H,W,3) uint8/float np or tensor; @ob_in_cams (N,4,4) np or tensor.  -> ((N,4,4) f32 device tensor, vis)"""
+                mesh_tensors=None, glctx=None, mesh_diameter=None, iteration=5, shared_translation=None):
+        """@rgb (H,W,3) uint8/float np or tensor; @ob_in_cams (N,4,4) np or tensor.  -> ((N,4,4) f32 device tensor, vis).
+        shared_translation (not in the reference's signature): True = the caller guarantees that all hypotheses have the
+        same translation (register()); None = found out here when ob_in_cams is host data (a device tensor is not read
+        back: treated as False); False = never share.  It only removes repeated work (refine_part), never changes a bit."""
         self.plan()
         dev = self._plan_dev
+        host = None
+        if isinstance(ob_in_cams, np.ndarray) or (torch.is_tensor(ob_in_cams) and ob_in_cams.device.type == "cpu"):
+            host = np.asarray(ob_in_cams, dtype=np.float32).reshape(-1, 4, 4)[:, :3, 3]
+            same = bool(host.shape[0] > 1 and (host == host[:1]).all())
+            if shared_translation and not same and host.shape[0] > 1:
+                raise ValueError("shared_translation=True, but the hypotheses do not have one translation")
+            if shared_translation is None:
+                shared_translation = same
         if mesh_tensors is None:
             mesh_tensors = make_mesh_tensors(mesh, device=dev)
         B_in_cams = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous()
@@ -244,7 +261,7 @@ class PoseRefinePredictor:
         xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
         H, W = int(rgb_t.shape[0]), int(rgb_t.shape[1])
         B_in_cams, trans, rot = self.refine_device(rgb_t, xyz_t, B_in_cams, K, H, W, get_mesh_handle(mesh_tensors),
-                                                   mesh_diameter, iteration)
+                                                   mesh_diameter, iteration, shared_translation=bool(shared_translation))
         self.last_trans_update = trans
         self.last_rot_update = rot
         if get_vis:

@@ -28,7 +28,8 @@ def test_shard_bounds():
 class _StubRefiner:
     """pose -> pose, row-wise deterministic (stands in for PoseRefinePredictor.predict)"""
 
-    def predict(self, rgb, depth, K, ob_in_cams, xyz_map, mesh=None, mesh_tensors=None, mesh_diameter=None, iteration=5):
+    def predict(self, rgb, depth, K, ob_in_cams, xyz_map, mesh=None, mesh_tensors=None, mesh_diameter=None, iteration=5,
+                shared_translation=None):
         P = torch.as_tensor(ob_in_cams, dtype=torch.float32).clone()
         P[:, :3, 3] += 0.01 * iteration * torch.sin(P[:, :3, 3] * 37.0)
         return P, None

@@ -555,6 +555,53 @@ def test_sub_batches_on_concurrent_streams_change_nothing(scene, dev, gmesh, fra
             assert torch.equal(res[1][4][k], res[ns][4][k])
 
 
+def test_shared_observed_crop_changes_nothing(scene, dev, gmesh, frame):
+    """register() starts every hypothesis at one translation, so in the first refine iteration all pairs have the same crop
+    window and the same observed crop: the refiner warps it once per sub-batch and the fp16 plan's stem encodes it once
+    (engine._HipEncoder shared_b).  Bit-identical to 75 separate copies, on one and on two streams, with the flag given, found
+    out from host poses, and for the two-pose quirk; poses with different translations never take the path."""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    rgb, depth, xyz = frame["rgb_t"], frame["depth_t"], frame["xyz_t"]
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+
+    def run(refiner, P, it, **k):
+        p, _ = refiner.predict(rgb, depth, scene["K"], P, xyz, iteration=it, **kw, **k)
+        return (p.clone(), refiner.last_trans_update.clone(), refiner.last_rot_update.clone(),
+                {n: v.clone() for n, v in refiner.last_raw_output.items()})
+
+    def same(a, b):
+        return all(torch.equal(x, y) for x, y in zip(a[:3], b[:3])) and all(torch.equal(a[3][n], b[3][n]) for n in a[3])
+
+    for ns in (1, 2):
+        refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev, n_streams=ns)
+        calls = []
+        plan = refiner.plan()
+        enc_call = plan.enc.__call__
+        plan.enc.__class__ = type("_CountingEncoder", (plan.enc.__class__,), {
+            "__call__": lambda self, AB, slot=0, shared_b=False: (calls.append((int(AB.shape[0]), bool(shared_b))), enc_call(AB, slot, shared_b))[1]})
+        for n, it in ((75, 1), (75, 3), (2, 2)):
+            P = scene["poses"][:n]
+            calls.clear()
+            ref = run(refiner, P, it, shared_translation=False)
+            assert not any(sh for _, sh in calls)
+            calls.clear()
+            auto = run(refiner, P, it)                                        # host poses: found out
+            parts = refiner.sub.parts(n, dev)
+            expect = [(b - a + 1, True) for a, b in parts if b - a > 1]
+            assert [c for c in calls if c[1]] == expect, (calls, expect)      # iteration 0 only, one shared crop per part
+            told = run(refiner, torch.as_tensor(P, device=dev), it, shared_translation=True)
+            assert same(ref, auto) and same(ref, told), (ns, n, it)
+        # different translations: host poses say so, and the flag is refused
+        Q = scene["poses"][:8].copy()
+        Q[3, 0, 3] += 1e-3
+        calls.clear()
+        run(refiner, Q, 1)
+        assert not any(sh for _, sh in calls)
+        with pytest.raises(ValueError):
+            run(refiner, Q, 1, shared_translation=True)
+
+
 def test_estimator_track_graph_matches_eager(scene, dev):
     from foundationpose_amd.estimater import FoundationPose
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
