@@ -240,6 +240,37 @@ __global__ __launch_bounds__(256) void k_rows_linear(const void* __restrict__ Xv
   }
 }
 
+// dst[c][r][0..C) = src[r][0..C) for c < copies: `rows` rows of C fp16 values at a row stride, 16 bytes per lane, every source
+// vector read once and stored `copies / gridDim.y` times by the same lane (torch.cat((a, b), 1) of refine_network.py:84 when all b
+// are one image: engine._HipEncoder shared_b)
+__global__ __launch_bounds__(256) void k_replicate_rows(const uint4* __restrict__ src, uint4* __restrict__ dst, int copies, int rows,
+                                                        int vec_per_row, int src_stride_v, int dst_stride_v, size_t copy_stride_v) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * vec_per_row) return;
+  const int r = idx / vec_per_row, v = idx - r * vec_per_row;
+  const uint4 val = src[(size_t)r * src_stride_v + v];
+  uint4* d = dst + (size_t)r * dst_stride_v + v;
+  for (int c = blockIdx.y; c < copies; c += gridDim.y) d[(size_t)c * copy_stride_v] = val;
+}
+
+extern "C" int fp_replicate_rows_f16(const void* src, void* dst, int copies, int rows, int channels, int src_row_stride,
+                                     int dst_row_stride, long long dst_copy_stride, void* stream) {
+  FP_REQUIRE(copies >= 0 && rows >= 0, "fp_replicate_rows_f16: negative size");
+  if (copies == 0 || rows == 0) return FP_OK;
+  FP_REQUIRE(src && dst, "fp_replicate_rows_f16: NULL tensor");
+  FP_REQUIRE(channels > 0 && channels % 8 == 0 && src_row_stride % 8 == 0 && dst_row_stride % 8 == 0 && dst_copy_stride % 8 == 0,
+             "fp_replicate_rows_f16: channels and strides must be multiples of 8 fp16 values (16-byte vectors)");
+  FP_REQUIRE(src_row_stride >= channels && dst_row_stride >= channels && dst_copy_stride > 0, "fp_replicate_rows_f16: bad strides");
+  FP_REQUIRE((((size_t)src | (size_t)dst) & 15) == 0, "fp_replicate_rows_f16: tensors must be 16-byte aligned");
+  FP_REQUIRE((long long)rows * (channels / 8) < (1ll << 31), "fp_replicate_rows_f16: rows * channels too large");
+  const int vpr = channels / 8;
+  const dim3 grid(fp_cdiv(rows * vpr, 256), copies < 16 ? copies : 16), block(256);
+  hipLaunchKernelGGL(k_replicate_rows, grid, block, 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, copies, rows, vpr,
+                     src_row_stride / 8, dst_row_stride / 8, (size_t)(dst_copy_stride / 8));
+  FP_CHECK_LAUNCH("fp_replicate_rows_f16");
+  return FP_OK;
+}
+
 extern "C" int fp_add_pe_f16_fwd(const void* tok, const float* pe, void* out, int M, int S, int D, void* stream) {
   FP_REQUIRE(M >= 0, "fp_add_pe_f16_fwd: M < 0");
   if (M == 0) return FP_OK;

@@ -237,7 +237,7 @@ class _HipEncoder:
         self._conv("s3b", b["T"], n2, h2, w2, 128, 128, b["CAT"], res=b["P3"],
                    gout=G(h2, w2, 1, 256, bsplit=n, cgroup=128), gres=G(h2, w2, 1, 128))
         if shared_b and n > 1:
-            b["CAT"][1:n, :, :, 128:].copy_(b["CAT"][0:1, :, :, 128:].expand(n - 1, -1, -1, -1))
+            ops.replicate_channels(b["CAT"], n, 128, 256)
         self._conv("j0a", b["CAT"], n, h2, w2, 256, 256, b["T2"])
         self._conv("j0b", b["T2"], n, h2, w2, 256, 256, b["J0"], res=b["CAT"])
         self._conv("j1a", b["J0"], n, h2, w2, 256, 256, b["T2"])

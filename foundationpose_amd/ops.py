@@ -331,6 +331,21 @@ def add_pe_f16(tok, pe):
     return out
 
 
+def replicate_channels(buf, n, c0, c1):
+    """buf (>= n, Hp, Wp, C) fp16 NHWC, contiguous: buf[1:n, :, :, c0:c1] = buf[0, :, :, c0:c1] (fp_replicate_rows_f16)"""
+    buf = _dev(buf, torch.float16, "buf")
+    if buf.dim() != 4 or not buf.is_contiguous() or buf.shape[0] < n:
+        raise _lib.FpAmdError(f"replicate_channels: buf must be a contiguous (>= {n}, Hp, Wp, C) tensor, got {tuple(buf.shape)}")
+    if n <= 1:
+        return buf
+    _, Hp, Wp, Ct = (int(v) for v in buf.shape)
+    src = buf.data_ptr() + 2 * int(c0)
+    st = _lib.lib().fp_replicate_rows_f16(C.c_void_p(src), C.c_void_p(src + 2 * Hp * Wp * Ct), int(n) - 1, Hp * Wp, int(c1) - int(c0), Ct, Ct,
+                                          Hp * Wp * Ct, _stream(buf))
+    _lib.check(st, "fp_replicate_rows_f16")
+    return buf
+
+
 def layernorm_res(branch16, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None, want32=True, want16=True):
     """LN(resid + f32(branch16)) * gamma + beta with resid = x32 or f32(tok16) + pe -> (y32 | None, y16 | None)
     (fp_layernorm_res_fwd: the fp32 residual stream / LayerNorms of nn.TransformerEncoderLayer under autocast)"""
@@ -508,6 +523,8 @@ pose_update = _timed("fp_pose_update", pose_update)
 conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu, _work_conv1)
 igemm_f16 = _timed("fp_igemm_f16_fwd", igemm_f16, _work_igemm)
 add_pe_f16 = _timed("fp_add_pe_f16_fwd", add_pe_f16, lambda tok, pe: (4.0 * tok.numel(), 0.0))
+replicate_channels = _timed("fp_replicate_rows_f16", replicate_channels,
+                            lambda buf, n, c0, c1: (2.0 * n * buf.shape[1] * buf.shape[2] * (c1 - c0), 0.0))
 layernorm_res = _timed("fp_layernorm_res_fwd", layernorm_res,
                        lambda br, *a, **k: ((2.0 + (4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
                                              + (2.0 if k.get("want16", True) else 0.0)) * br.numel(), 0.0))

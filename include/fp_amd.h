@@ -177,6 +177,14 @@ int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/
  * recomputes it.) */
 int fp_add_pe_f16_fwd(const void* tok /*dev*/, const float* pe /*dev*/, void* out /*dev*/, int M, int S, int D, void* stream);
 
+/* refine_network.py:82-85 `ab = torch.cat((a, b), 1)` when every b is ONE image -- the first refine iteration of
+ * estimater.py:214-215 register(), whose hypotheses share a translation (estimater.py:132-133) and therefore the observed
+ * crop: dst[c][r][0..channels) = src[r][0..channels) for c < copies.  fp16 rows at row strides (in fp16 values; channels and
+ * all strides multiples of 8, pointers 16-byte aligned), copy c at dst + c * dst_copy_stride.  src and dst may be
+ * different images of one buffer as long as the source rows are not among the destination rows. */
+int fp_replicate_rows_f16(const void* src /*dev*/, void* dst /*dev*/, int copies, int rows, int channels, int src_row_stride,
+                          int dst_row_stride, long long dst_copy_stride, void* stream);
+
 /* The LayerNorms of nn.TransformerEncoderLayer (refine_network.py:56-70; post-norm, eps 1e-5) on the fp32 residual
  * stream autocast keeps:  z = resid + f32(branch16);  y = LN(z)*gamma + beta  -> y32 (M,D) f32 and/or y16 (M,D) f16,
  * with resid = x32 (M,D) f32, or f32(tok16) + pe[row % S] when x32 is NULL.  D must be 512. */

@@ -58,6 +58,10 @@ def test_argument_errors_are_reported_without_gpu():
     assert lib.fp_layernorm_res_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,
                                     C.c_void_p(16), None, 4, 512, None) == -1     # residual given twice
     assert lib.fp_attention_f16_fwd(C.c_void_p(16), C.c_void_p(16), 1, 4, 4, 128, 2, None) == -1
+    assert lib.fp_replicate_rows_f16(C.c_void_p(16), C.c_void_p(32), 3, 10, 100, 256, 256, 2560, None) == -1      # 100 channels
+    assert b"multiples of 8" in lib.fp_last_error()
+    assert lib.fp_replicate_rows_f16(C.c_void_p(16), C.c_void_p(32), 3, 10, 128, 64, 256, 2560, None) == -1       # stride < channels
+    assert lib.fp_replicate_rows_f16(C.c_void_p(16), C.c_void_p(32), 0, 10, 128, 256, 256, 2560, None) == 0       # nothing to do
     # fp_render_crops defines two flag bits; anything else (e.g. the phase-skip bits of the profiling build) is refused
     for bad in (0x10000, 0x80000, 4):
         assert lib.fp_render_crops(None, None, None, None, 480, 640, 0, 160, 160, 0.8, 0.5, 0.17, 0.001, 3 | bad, None, None, None, None,

@@ -555,6 +555,18 @@ def test_sub_batches_on_concurrent_streams_change_nothing(scene, dev, gmesh, fra
             assert torch.equal(res[1][4][k], res[ns][4][k])
 
 
+def test_replicate_channels(dev):
+    """fp_replicate_rows_f16: one image's channel group copied into the same group of the following images, nothing else touched"""
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for n, hp, wp, ct, c0, c1 in ((7, 42, 42, 256, 128, 256), (2, 5, 3, 64, 0, 8), (40, 9, 9, 512, 256, 320), (1, 4, 4, 16, 8, 16)):
+        buf = torch.randn((n + 1, hp, wp, ct), generator=g).to(torch.float16).to(dev)
+        want = buf.clone()
+        want[1:n, :, :, c0:c1] = want[0:1, :, :, c0:c1]
+        ops.replicate_channels(buf, n, c0, c1)
+        assert torch.equal(buf, want), (n, hp, wp, ct, c0, c1)       # incl. the image after the last copy: untouched
+
+
 def test_shared_observed_crop_changes_nothing(scene, dev, gmesh, frame):
     """register() starts every hypothesis at one translation, so in the first refine iteration all pairs have the same crop
     window and the same observed crop: the refiner warps it once per sub-batch and the fp16 plan's stem encodes it once
