@@ -95,6 +95,21 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
     return batch
 
 
+def resolve_shared_translation(ob_in_cams, flag):
+    """-> bool: may the first refine iteration treat the hypotheses as sharing one translation (PoseRefinePredictor.predict)?
+    flag True: the caller says so (checked when the poses are host data); None: decided from host poses -- compared as the
+    float32 values that are uploaded -- and False for a device tensor, which is never read back; False: no."""
+    on_host = isinstance(ob_in_cams, np.ndarray) or (torch.is_tensor(ob_in_cams) and ob_in_cams.device.type == "cpu") or \
+        isinstance(ob_in_cams, (list, tuple))
+    if not on_host:
+        return bool(flag)
+    t = np.asarray(ob_in_cams, dtype=np.float32).reshape(-1, 4, 4)[:, :3, 3]
+    same = bool(t.shape[0] > 1 and (t == t[:1]).all())
+    if flag and t.shape[0] > 1 and not same:
+        raise ValueError("shared_translation=True, but the hypotheses do not have one translation")
+    return same if flag is None else bool(flag) and same
+
+
 class PoseRefinePredictor:
     run_name = "2023-10-28-18-33-37"
 
@@ -246,14 +261,7 @@ class PoseRefinePredictor:
         back: treated as False); False = never share.  It only removes repeated work (refine_part), never changes a bit."""
         self.plan()
         dev = self._plan_dev
-        host = None
-        if isinstance(ob_in_cams, np.ndarray) or (torch.is_tensor(ob_in_cams) and ob_in_cams.device.type == "cpu"):
-            host = np.asarray(ob_in_cams, dtype=np.float32).reshape(-1, 4, 4)[:, :3, 3]
-            same = bool(host.shape[0] > 1 and (host == host[:1]).all())
-            if shared_translation and not same and host.shape[0] > 1:
-                raise ValueError("shared_translation=True, but the hypotheses do not have one translation")
-            if shared_translation is None:
-                shared_translation = same
+        shared_translation = resolve_shared_translation(ob_in_cams, shared_translation)
         if mesh_tensors is None:
             mesh_tensors = make_mesh_tensors(mesh, device=dev)
         B_in_cams = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous()
