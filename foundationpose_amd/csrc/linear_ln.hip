@@ -1,0 +1,261 @@
+// fp_linear_layernorm_fwd -- a 512-wide Linear of nn.TransformerEncoderLayer (refine_network.py:56-70: self_attn.out_proj,
+// linear2) fused with the residual add and the post-norm LayerNorm that consume it:
+//     branch = f16(x16 @ W^T + b)                    (nn.Linear under autocast: fp32 accumulate + bias, one rounding)
+//     z      = resid + f32(branch)                   (fp32 residual stream; resid = x32, or f32(tok16) + pe[row % S])
+//     y      = LN(z) * gamma + beta  -> y32 and / or y16
+// = fp_igemm_f16_fwd (taps = 1) followed by fp_layernorm_res_fwd, without the (M, 512) branch tensor ever reaching HBM and
+// without the second launch.  A workgroup owns 128 complete rows (tile 128 x 512, so the LayerNorm statistics of a row stay
+// inside the workgroup): 8 waves, wave w computes channels [64 w, 64 w + 64) of all 128 rows as 4 x 2
+// v_mfma_f32_32x32x16_f16 tiles (128 accumulator registers); main loop = the lock-step schedule of k_igemm_f16 (igemm.hip)
+// at BK = 32 with 3 LDS stages (operands HBM -> LDS by LDS-DMA, XOR-swizzled 64-byte rows, counted vmcnt + one barrier per
+// k-step); the epilogue parks f16(acc + bias) in the swizzled LDS tile of igemm_epilogue.h (128 rows x 1 KiB) and then runs
+// the row code of k_layernorm_res512 (rowops_ln.h, the same source) on those rows, 16 rows per wave, four at a time.
+// Per element the same instruction sequence as the two-kernel path it replaces.
+#include <hip/hip_fp16.h>
+#include "igemm_common.h"
+#include "rowops_ln.h"
+
+namespace {
+
+constexpr int LL_BM = 128, LL_BN = 512, LL_TM = 4, LL_NW = 8, LL_THREADS = LL_NW * 64, LL_BK = 32, LL_NST = 3;
+constexpr int LL_ROWB = LL_BK * 2;                       // bytes per LDS row (one input row / one output channel, BK halves)
+constexpr int LL_KK = LL_BK / 16;                        // MFMA k-substeps per stage
+constexpr int LL_A_BYTES = LL_BM * LL_ROWB;              // 8 KiB
+constexpr int LL_W_BYTES = LL_BN * LL_ROWB;              // 32 KiB
+constexpr int LL_STAGE = LL_A_BYTES + LL_W_BYTES;        // 40 KiB
+constexpr int LL_E_BYTES = LL_BM * LL_BN * 2;            // 128 KiB: the epilogue tile, laid over the (finished) staging buffers
+constexpr int LL_MAIN = LL_NST * LL_STAGE > LL_E_BYTES ? LL_NST * LL_STAGE : LL_E_BYTES;
+constexpr int LL_LDS = LL_MAIN + LL_BN * 4;              // + the bias vector
+constexpr int LL_WI = 4;                                 // W-tile LDS-DMA instructions per wave and stage (A tile: one)
+constexpr int LL_ROWS_PER_WAVE = LL_BM / LL_NW;          // 16
+constexpr int LL_R = 4;                                  // rows a wave normalises together (interleaved reduction chains)
+static_assert(LL_LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+
+struct LinearLnParams {
+  const _Float16* X;      // (M, K)
+  const _Float16* Wt;     // (512, K)
+  const float* bias;      // (512) or null
+  const float* x32;       // residual stream (M, 512) f32, or null
+  const _Float16* tok16;  // ... or tokens (M, 512) f16 + pe
+  const float* pe;
+  int S;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float* y32;             // either may be null
+  _Float16* y16;
+  int M, K;
+};
+
+__device__ __forceinline__ int ll_swz(int row) { return (row >> 2) & 3; }   // chunk swizzle of a 64-byte row (4 rows per bank row)
+
+__global__ __launch_bounds__(LL_THREADS, 1) void k_linear_ln512(LinearLnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = channel group of 64
+  float* bias_lds = reinterpret_cast<float*>(smem + LL_MAIN);
+  const int m0 = blockIdx.x * LL_BM;
+
+  // bias -> LDS (512 floats: waves 0 and 1 fetch 1 KiB each with one LDS-DMA; the oldest vector-memory operation of the wave,
+  // so every later counted wait covers it; visible to the workgroup after the first barrier of the main loop)
+  if (wid < 2) {
+    float* dst = bias_lds + wid * 256;
+    if (p.bias) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, LL_BN * 4, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, wid * 1024, 0, 0);
+    } else {
+      *reinterpret_cast<float4_*>(dst + lane * 4) = float4_{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // per-thread staging sources (byte offsets from the tensor bases): wave w loads rows [16 w, +16) of the A tile and rows
+  // [64 w, +64) of W; an LDS-DMA instruction writes 1 KiB lane-linear = 16 rows of 64 B, so lane l carries row l / 4 and the
+  // LOGICAL chunk that belongs in physical chunk l % 4 of that row
+  unsigned aoff32, woff32[LL_WI];
+  {
+    const int row = wid * 16 + lane / 4;
+    const int c = (lane % 4) ^ ll_swz(row);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    aoff32 = (unsigned)(((size_t)m * p.K + c * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < LL_WI; ++j) {
+    const int row = wid * 64 + j * 16 + lane / 4;
+    const int c = (lane % 4) ^ ll_swz(row);
+    woff32[j] = (unsigned)(((size_t)row * p.K + c * 8) * 2);
+  }
+  const int nk = p.K / LL_BK;
+  int st_k = 0;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.X), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Wt), 0, 0x7FFFFFFF, 0x00020000);
+  auto stage = [&](int buf) {
+    const int soff = st_k * (LL_BK * 2);
+    unsigned char* sa = smem + buf * LL_STAGE + wid * 1024;
+    unsigned char* sw = smem + buf * LL_STAGE + LL_A_BYTES + wid * (LL_WI * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)sa, 16, (int)aoff32, soff, 0, 0);
+#pragma unroll
+    for (int j = 0; j < LL_WI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sw + j * 1024), 16, (int)woff32[j],
+                                               soff, 0, 0);
+    ++st_k;
+  };
+
+  float16_ acc[2][LL_TM];   // [channel tile i][row tile j]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < LL_TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read addressing: lane reads row (lane & 31) of a 32-row tile, logical chunk 2 kk + (lane >> 5)
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int a_off[LL_TM][LL_KK], w_off[2][LL_KK];
+#pragma unroll
+  for (int t = 0; t < LL_TM; ++t) {
+    const int ra = t * 32 + frow;
+#pragma unroll
+    for (int kk = 0; kk < LL_KK; ++kk) a_off[t][kk] = ra * LL_ROWB + (((2 * kk + fhalf) ^ ll_swz(ra)) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rw = wid * 64 + t * 32 + frow;
+#pragma unroll
+    for (int kk = 0; kk < LL_KK; ++kk) w_off[t][kk] = LL_A_BYTES + rw * LL_ROWB + (((2 * kk + fhalf) ^ ll_swz(rw)) << 4);
+  }
+
+#pragma unroll
+  for (int s = 0; s < LL_NST - 1; ++s)
+    if (s < nk) stage(s);
+  int buf = 0, nbuf = LL_NST - 1;
+  for (int ks = 0; ks < nk; ++ks) {
+    // stage ks must have landed; the stage issued after it (1 + LL_WI loads per wave) may stay in flight
+    if (ks + LL_NST - 2 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // everyone's part of stage ks is visible; everyone is done reading stage ks-1
+    if (ks + LL_NST - 1 < nk) stage(nbuf);
+    const unsigned char* sb = smem + buf * LL_STAGE;
+    half8 fa[2][LL_TM], fw[2][2];
+    auto load_frags = [&](int kk, int slot) {
+#pragma unroll
+      for (int t = 0; t < LL_TM; ++t) fa[slot][t] = *reinterpret_cast<const half8*>(sb + a_off[t][kk]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) fw[slot][t] = *reinterpret_cast<const half8*>(sb + w_off[t][kk]);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < LL_KK; ++kk) {
+      if (kk < LL_KK - 1) load_frags(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < LL_TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk & 1][i], fa[kk & 1][j], acc[i][j], 0, 0, 0);
+    }
+    buf = (buf + 1 == LL_NST) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == LL_NST) ? 0 : nbuf + 1;
+  }
+  __syncthreads();   // all fragment reads done before the staging buffers become the epilogue tile
+
+  // residual rows (fp32 stream, or fp16 tokens + positional table) of LL_R rows of this wave, rows wid + 8 (t0 + u); a row
+  // past the end of the matrix reads the last row instead: normalised, never stored
+  half8 tk[LL_R];
+  float rs[LL_R][8];
+  auto request_resid = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < LL_R; ++u) {
+      const int m = m0 + wid + LL_NW * (t0 + u);
+      const int mc = m < p.M ? m : p.M - 1;
+      if (p.x32) {
+        load8f(p.x32 + (size_t)mc * 512 + lane * 8, rs[u]);
+      } else {
+        tk[u] = *reinterpret_cast<const half8*>(p.tok16 + (size_t)mc * 512 + lane * 8);
+        load8f(p.pe + (size_t)((unsigned)mc % (unsigned)p.S) * 512 + lane * 8, rs[u]);
+      }
+    }
+  };
+  request_resid(0);   // in flight under the transposition below
+
+  // ---- epilogue 1: f16(acc + bias) -> E[row][channel], rows of 1 KiB, the low 4 bits of the 16-byte chunk index XORed with
+  // (row & 15) (igemm_epilogue.h).  D[i = channel][j = row]: a lane holds row (lane & 31) of a row tile and channels
+  // 8 g + 4 (lane >> 5) + {0..3} of a channel tile, g = register >> 2
+  unsigned char* E = smem;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = wid * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
+      const float4_ bv = *reinterpret_cast<const float4_*>(bias_lds + nl);
+#pragma unroll
+      for (int j = 0; j < LL_TM; ++j) {
+        const int ml = j * 32 + (lane & 31);
+        half4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
+        const int chunk = (nl >> 3) ^ (ml & 15);
+        *reinterpret_cast<half4*>(E + ml * (2 * LL_BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: k_layernorm_res512's row code on the tile's rows (wave w: rows w, w + 8, ...), LL_R rows at a time.
+  // The residual rows of the NEXT group are requested before the current group is normalised (and those of the first group
+  // before the accumulators are parked, see above), so a wave waits for HBM once, not four times; row numbers are wave-uniform:
+  // the positional-table row costs a scalar 32-bit modulo, where resid_row's 64-bit one would be a division loop per row.
+  float gm[8], bt[8];
+  load8f(p.gamma + lane * 8, gm);
+  load8f(p.beta + lane * 8, bt);
+#pragma unroll 1
+  for (int t0 = 0; t0 < LL_ROWS_PER_WAVE; t0 += LL_R) {
+    float f[LL_R][8];
+#pragma unroll
+    for (int u = 0; u < LL_R; ++u) {
+      const int r = wid + LL_NW * (t0 + u);
+      const half8 b = *reinterpret_cast<const half8*>(E + r * (2 * LL_BN) + ((lane ^ (r & 15)) << 4));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        f[u][e] = p.x32 ? rs[u][e] : (float)tk[u][e] + rs[u][e];     // resid_row (rowops_ln.h)
+        f[u][e] += (float)b[e];
+      }
+    }
+    if (t0 + LL_R < LL_ROWS_PER_WAVE) request_resid(t0 + LL_R);
+    ln_rows<LL_R>(p.eps, f);
+#pragma unroll
+    for (int u = 0; u < LL_R; ++u) {
+      const int m = m0 + wid + LL_NW * (t0 + u);
+      if (m >= p.M) continue;                              // wave-uniform
+      half8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { f[u][e] = fmaf(f[u][e], gm[e], bt[e]); h[e] = (_Float16)f[u][e]; }
+      if (p.y32) store8f(p.y32 + (size_t)m * 512 + lane * 8, f[u]);
+      if (p.y16) *reinterpret_cast<half8*>(p.y16 + (size_t)m * 512 + lane * 8) = h;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int fp_linear_layernorm_fwd(const void* x16, const void* w16, const float* bias, const float* x32, const void* tok16,
+                                       const float* pe, int S, const float* gamma, const float* beta, float eps, float* y32,
+                                       void* y16, int M, int K, int D, void* stream) {
+  FP_REQUIRE(M >= 0, "fp_linear_layernorm_fwd: M < 0");
+  if (M == 0) return FP_OK;
+  FP_REQUIRE(x16 && w16 && gamma && beta && (y32 || y16), "fp_linear_layernorm_fwd: NULL tensor");
+  FP_REQUIRE((x32 != nullptr) != (tok16 != nullptr), "fp_linear_layernorm_fwd: give the residual as x32 OR as tok16 (+ pe)");
+  FP_REQUIRE(x32 || (pe && S > 0), "fp_linear_layernorm_fwd: tok16 needs the positional table and its period");
+  FP_REQUIRE(D == 512, "fp_linear_layernorm_fwd: D=%d unsupported (d_model of both networks is 512)", D);
+  FP_REQUIRE(K > 0 && K % LL_BK == 0, "fp_linear_layernorm_fwd: K=%d must be a multiple of %d", K, LL_BK);
+  FP_REQUIRE((long long)M * K < (1ll << 30) && (long long)D * K < (1ll << 30), "fp_linear_layernorm_fwd: operands exceed 2 GiB");
+  FP_REQUIRE((((size_t)x16 | (size_t)w16 | (size_t)bias | (size_t)x32 | (size_t)tok16 | (size_t)pe | (size_t)gamma | (size_t)beta |
+               (size_t)y32 | (size_t)y16) & 15) == 0, "fp_linear_layernorm_fwd: tensors must be 16-byte aligned");
+  LinearLnParams p;
+  p.X = (const _Float16*)x16; p.Wt = (const _Float16*)w16; p.bias = bias; p.x32 = x32; p.tok16 = (const _Float16*)tok16; p.pe = pe;
+  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.K = K;
+  FP_SET_MAX_LDS(k_linear_ln512, LL_LDS);
+  hipLaunchKernelGGL(k_linear_ln512, dim3(fp_cdiv(M, LL_BM)), dim3(LL_THREADS), LL_LDS, (hipStream_t)stream, p);
+  FP_CHECK_LAUNCH("fp_linear_layernorm_fwd");
+  return FP_OK;
+}

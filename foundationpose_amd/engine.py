@@ -34,6 +34,8 @@ policy that tests/test_gpu_amp.py puts next to the HIP plan and the oracle, and 
 """
 import contextlib
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -44,6 +46,12 @@ from . import ops
 # N=252 takes minutes).  The two torch configurations therefore run their convolutions on ATen's own path (im2col +
 # rocBLAS GEMM, what PyTorch uses when `torch.backends.cudnn` is disabled) unless MIOpen is asked for explicitly.
 USE_MIOPEN = False
+
+
+# out_proj + residual + LayerNorm of the refiner's encoder layers as ONE kernel (csrc/linear_ln.hip, fp_linear_layernorm_fwd):
+# bit-identical to the two launches it replaces (tests/test_gpu_parity.py::test_linear_layernorm_is_the_two_kernel_path) and
+# 0.6-1.4 % of the step faster.  FP_AMD_FUSED_LN=0 goes back to fp_igemm_f16_fwd + fp_layernorm_res_fwd.
+FUSED_OUT_PROJ_LN = os.environ.get("FP_AMD_FUSED_LN", "1") != "0"
 
 
 def _conv_backend():
@@ -311,8 +319,13 @@ class _HipEncoderLayer:
 
     def pooled(self, tok16, x16, pe):
         """-> mean over the tokens of the layer output, (N, 512) fp32"""
-        sa = self.att(x16)                                                       # fp16
-        y32, y16 = ops.layernorm_res(sa, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)   # LN(x + sa): fp32 stream + fp16 copy
+        if FUSED_OUT_PROJ_LN:
+            # out_proj + residual + norm1 in one launch, the projection staying on chip (fp_linear_layernorm_fwd): the same bits
+            y32, y16 = ops.linear_layernorm_res(self.att.context(x16), self.att.out.w, self.att.out.b, self.n1[0], self.n1[1], 1e-5,
+                                                tok16=tok16, pe=pe)
+        else:
+            sa = self.att(x16)                                                   # fp16
+            y32, y16 = ops.layernorm_res(sa, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)   # LN(x + sa): fp32 stream + fp16 copy
         ff = self.l2(self.l1(y16, relu=True))
         return ops.colmean_f16(ff, self.n2[0], self.n2[1], 1e-5, resid32=y32)    # mean_t LN(y + ff)
 

@@ -362,6 +362,28 @@ def layernorm_res(branch16, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None
     return y32, y16
 
 
+def linear_layernorm_res(x16, w16, bias, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None, want32=True, want16=True):
+    """layernorm_res(f16(x16 @ w16^T + bias), ...) in ONE launch, the product staying on chip (fp_linear_layernorm_fwd).
+    x16 (..., K) fp16, w16 (512, K) fp16 -> (y32 | None, y16 | None) of shape (..., 512); bit-identical to the two-kernel path"""
+    x = _dev(x16, torch.float16, "x16")
+    w = _dev(w16, torch.float16, "w16")
+    K = int(x.shape[-1])
+    D = int(w.shape[0])
+    if w.dim() != 2 or int(w.shape[1]) != K:
+        raise _lib.FpAmdError(f"linear_layernorm_res: w16 {tuple(w.shape)} does not match x16 (..., {K})")
+    M = x.numel() // K
+    x32 = _dev(x32, torch.float32, "x32"); tok16 = _dev(tok16, torch.float16, "tok16"); pe = _dev(pe, torch.float32, "pe")
+    S = int(pe.shape[-2]) if pe is not None else 0
+    shape = tuple(x.shape[:-1]) + (D,)
+    y32 = torch.empty(shape, dtype=torch.float32, device=x.device) if want32 else None
+    y16 = torch.empty(shape, dtype=torch.float16, device=x.device) if want16 else None
+    st = _lib.lib().fp_linear_layernorm_fwd(_ptr(x), _ptr(w), _ptr(_dev(bias, torch.float32, "bias")), _ptr(x32), _ptr(tok16), _ptr(pe), S,
+                                            _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")), float(eps),
+                                            _ptr(y32), _ptr(y16), M, K, D, _stream(x))
+    _lib.check(st, "fp_linear_layernorm_fwd")
+    return y32, y16
+
+
 def colmean_f16(x, gamma=None, beta=None, eps=1e-5, resid32=None):
     """x (G, R, 512) fp16 -> (G, 512) f32: mean over R of LN(resid32 + x)*gamma+beta (gamma given) or of x (fp_colmean_f16_fwd)"""
     x = _dev(x, torch.float16, "x")
@@ -528,6 +550,11 @@ replicate_channels = _timed("fp_replicate_rows_f16", replicate_channels,
 layernorm_res = _timed("fp_layernorm_res_fwd", layernorm_res,
                        lambda br, *a, **k: ((2.0 + (4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
                                              + (2.0 if k.get("want16", True) else 0.0)) * br.numel(), 0.0))
+linear_layernorm_res = _timed("fp_linear_layernorm_fwd", linear_layernorm_res,
+                              lambda x, w, *a, **k: (2.0 * x.numel() + 2.0 * w.numel() + (x.numel() // x.shape[-1]) * w.shape[0] *
+                                                     ((4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
+                                                      + (2.0 if k.get("want16", True) else 0.0)),
+                                                     2.0 * x.numel() * w.shape[0]))
 colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16,
                      lambda x, *a, **k: ((6.0 if k.get("resid32") is not None else 2.0) * x.numel(), 0.0))
 rows_linear = _timed("fp_rows_linear_fwd", rows_linear)

@@ -192,6 +192,16 @@ int fp_layernorm_res_fwd(const float* x32 /*dev|NULL*/, const void* tok16 /*dev|
                          const void* branch16 /*dev*/, const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps,
                          float* y32 /*dev|NULL*/, void* y16 /*dev|NULL*/, int M, int D, void* stream);
 
+/* A 512-wide nn.Linear of the encoder layer (refine_network.py:56-70: self_attn.out_proj or linear2, under autocast: fp16
+ * operands, fp32 accumulation + bias, one rounding to fp16) fused with the residual add and the LayerNorm that consume it:
+ * fp_igemm_f16_fwd (taps = 1, N = 512) followed by fp_layernorm_res_fwd with branch16 = that product, in one launch and
+ * without the (M, 512) product reaching HBM; per element the same instruction sequence, i.e. the same bits.
+ * x16 (M, K) fp16, w16 (512, K) fp16 (PyTorch layout), bias (512) f32 | NULL; the other arguments as fp_layernorm_res_fwd. */
+int fp_linear_layernorm_fwd(const void* x16 /*dev*/, const void* w16 /*dev*/, const float* bias /*dev|NULL*/,
+                            const float* x32 /*dev|NULL*/, const void* tok16 /*dev|NULL*/, const float* pe /*dev|NULL*/, int S,
+                            const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps, float* y32 /*dev|NULL*/,
+                            void* y16 /*dev|NULL*/, int M, int K, int D, void* stream);
+
 /* `.mean(dim=1)` over the tokens of each hypothesis (refine_network.py:90-91, score_network.py:74), optionally fused
  * with the residual add + LayerNorm that precede it: out[g, :] = mean_{r < rows_per_group} f(row g*rows_per_group + r),
  * f = LN(resid32 + f32(x))*gamma + beta if gamma != NULL (resid32 may be NULL) else f32(x).  x (groups*rows_per_group, D)

@@ -555,6 +555,32 @@ def test_sub_batches_on_concurrent_streams_change_nothing(scene, dev, gmesh, fra
             assert torch.equal(res[1][4][k], res[ns][4][k])
 
 
+def test_linear_layernorm_is_the_two_kernel_path(dev):
+    """fp_linear_layernorm_fwd (out_proj / linear2 + residual + LayerNorm in one launch) returns the bits of
+    fp_igemm_f16_fwd followed by fp_layernorm_res_fwd: both residual forms, full and ragged row counts, one or both outputs"""
+    from foundationpose_amd import ops
+    from foundationpose_amd.engine import _HipLinear
+    g = torch.Generator(device="cpu").manual_seed(11)
+    w = (torch.randn((512, 512), generator=g) * 0.05)
+    b = torch.randn((512,), generator=g) * 0.1
+    lin = _HipLinear(w.to(dev), b.to(dev))
+    gamma = (1.0 + 0.1 * torch.randn((512,), generator=g)).to(dev)
+    beta = (0.1 * torch.randn((512,), generator=g)).to(dev)
+    pe = torch.randn((400, 512), generator=g).to(dev)
+    for n_seq, S in ((126, 400), (3, 400), (1, 77)):
+        M = n_seq * S
+        x = torch.randn((n_seq, S, 512), generator=g).to(torch.float16).to(dev)
+        tok = torch.randn((n_seq, S, 512), generator=g).to(torch.float16).to(dev)
+        x32 = torch.randn((n_seq, S, 512), generator=g).to(dev)
+        for kw in (dict(tok16=tok, pe=pe[:S].contiguous()), dict(x32=x32)):
+            br = lin(x)
+            want32, want16 = ops.layernorm_res(br, gamma, beta, 1e-5, **kw)
+            got32, got16 = ops.linear_layernorm_res(x, lin.w, lin.b, gamma, beta, 1e-5, **kw)
+            assert torch.equal(got32, want32) and torch.equal(got16, want16), (M, list(kw))
+            only16 = ops.linear_layernorm_res(x, lin.w, lin.b, gamma, beta, 1e-5, want32=False, **kw)
+            assert only16[0] is None and torch.equal(only16[1], want16)
+
+
 def test_replicate_channels(dev):
     """fp_replicate_rows_f16: one image's channel group copied into the same group of the following images, nothing else touched"""
     from foundationpose_amd import ops
