@@ -320,26 +320,6 @@ def test_plans_match_amp_oracle(dev):
     assert np.abs(logits - lref).max() <= 0.05 * max(1.0, lref.std()) + 4 * ulp16(np.abs(lref).max()), (logits, lref)
 
 
-def test_fused_out_proj_layernorm_changes_nothing_in_the_plan(dev, monkeypatch):
-    """engine.FUSED_OUT_PROJ_LN (fp_linear_layernorm_fwd instead of fp_igemm_f16_fwd + fp_layernorm_res_fwd in the refiner's
-    encoder layers): the same bits out of the whole plan"""
-    from foundationpose_amd import engine
-    from foundationpose_amd.refine_network import RefineNet
-    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
-    n = 5
-    AB = _net_inputs(n, 4).half().to(dev)
-    cfg = dict(DEFAULT_REFINE_CFG)
-    net = RefineNet(cfg=cfg, c_in=6)
-    net.load_state_dict(random_state_dict("refine", cfg, 0))
-    plan = engine.RefinePlan(net, dev, precision="fp16")
-    outs = {}
-    for fused in (True, False):
-        monkeypatch.setattr(engine, "FUSED_OUT_PROJ_LN", fused)
-        outs[fused] = {k: v.clone() for k, v in plan(AB).items()}
-    for k in outs[True]:
-        assert torch.equal(outs[True][k], outs[False][k]), k
-
-
 # ------------------------------------------------------------------ 3. BASELINE size
 @pytest.fixture(scope="module")
 def gmesh(scene, dev):
