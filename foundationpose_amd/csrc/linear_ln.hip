@@ -58,6 +58,7 @@ struct LinearLnParams {
   float* y32;             // either may be null
   _Float16* y16;
   int M, K;
+  float* part;            // MEAN variant (profiling build): per-tile partial column sums [tiles][2][512]; S = rows per group
 };
 
 __device__ __forceinline__ int ll_swz(int row) { return (row >> 2) & 3; }   // chunk swizzle of a 64-byte row (4 rows per bank row)
@@ -68,7 +69,10 @@ __device__ __forceinline__ void ll_dma16(const __amdgpu_buffer_rsrc_t& rs, void*
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int BM, int NST>
+// MEAN (profiling build only, fp_linear_layernorm_mean_fwd): instead of writing the normalised rows, add them up per group of
+// p.S rows (the token mean of refine_network.py:90-91 fused with norm2): per-tile partial column sums, finished by
+// k_ln_mean_finish in a fixed order.
+template <int BM, int NST, bool MEAN = false>
 __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU)) void k_linear_ln512(LinearLnParams p) {
   using T = LlTile<BM, NST>;
   constexpr int LL_BM = BM, LL_NST = NST, LL_TM = T::TM, LL_A_BYTES = T::A_BYTES, LL_STAGE = T::STAGE, LL_MAIN = T::MAIN;
@@ -230,8 +234,18 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU)) void k_li
   // before the accumulators are parked, see above), so a wave waits for HBM once, not four times; row numbers are wave-uniform:
   // the positional-table row costs a scalar 32-bit modulo, where resid_row's 64-bit one would be a division loop per row.
   float gm[8], bt[8];
-  load8f(p.gamma + lane * 8, gm);
-  load8f(p.beta + lane * 8, bt);
+  if constexpr (!MEAN) {
+    load8f(p.gamma + lane * 8, gm);
+    load8f(p.beta + lane * 8, bt);
+  }
+  // MEAN: a tile of BM <= p.S rows touches at most two groups; rows below `second_group_row` belong to the first
+  float csum[2][8];
+  int second_group_row = 0;
+  if constexpr (MEAN) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { csum[0][e] = 0.f; csum[1][e] = 0.f; }
+    second_group_row = (m0 / p.S + 1) * p.S;
+  }
 #pragma unroll 1
   for (int t0 = 0; t0 < LL_ROWS_PER_WAVE; t0 += LL_R) {
     float f[LL_R][8];
@@ -247,6 +261,21 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU)) void k_li
     }
     if (t0 + LL_R < LL_ROWS_PER_WAVE) request_resid(t0 + LL_R);
     ln_rows<LL_R>(p.eps, f);
+    if constexpr (MEAN) {
+#pragma unroll
+      for (int u = 0; u < LL_R; ++u) {
+        const int m = m0 + wid + LL_NW * (t0 + u);
+        if (m >= p.M) continue;                            // wave-uniform
+        if (m < second_group_row) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[0][e] += f[u][e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[1][e] += f[u][e];
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < LL_R; ++u) {
       const int m = m0 + wid + LL_NW * (t0 + u);
@@ -258,7 +287,39 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU)) void k_li
       if (p.y16) *reinterpret_cast<half8*>(p.y16 + (size_t)m * 512 + lane * 8) = h;
     }
   }
+  if constexpr (MEAN) {
+    // wave partials -> LDS (the E tile is free once every wave has read its rows) -> one thread per channel adds the eight
+    // waves in order -> this tile's two partial sums
+    __syncthreads();
+    float* P = reinterpret_cast<float*>(smem);   // [wave][slot][512]
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) store8f(P + (wid * 2 + sl) * 512 + lane * 8, csum[sl]);
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < LL_NW; ++w) a += P[(w * 2 + sl) * 512 + tid];
+      p.part[((size_t)blockIdx.x * 2 + sl) * 512 + tid] = a;
+    }
+  }
 }
+
+#ifdef FP_PROFILE_BUILD
+// out[g][c] = mean over the rows of group g of LN(...) * gamma + beta from the tiles' partial sums, tiles in increasing order
+__global__ __launch_bounds__(512) void k_ln_mean_finish(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ out, int S, int BM) {
+  const int g = blockIdx.x, c = threadIdx.x;
+  const int t_first = (g * S) / BM, t_last = ((g + 1) * S - 1) / BM;
+  float a = 0.f;
+  for (int t = t_first; t <= t_last; ++t) {
+    const int sl = g - (t * BM) / S;            // 0: the group the tile starts in, 1: the next one
+    a += part[((size_t)t * 2 + sl) * 512 + c];
+  }
+  a *= 1.0f / (float)S;
+  out[(size_t)g * 512 + c] = fmaf(a, gamma[c], beta[c]);   // mean(LN(x) * gamma + beta) = mean(LN(x)) * gamma + beta
+}
+#endif
 
 template <int BM, int NST>
 int ll_launch(const LinearLnParams& p, hipStream_t stream) {
@@ -270,6 +331,37 @@ int ll_launch(const LinearLnParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef FP_PROFILE_BUILD
+// Profiling build only (not in include/fp_amd.h, bound ad hoc by scripts/bench_linear_ln_mean.py): linear2 + residual + norm2 +
+// token mean of the refiner's encoder layer in one launch + a finish kernel; = fp_igemm_f16_fwd + fp_colmean_f16_fwd with another
+// (fixed) summation order of the token mean, so it has to pass the parity gates before it can replace them.
+// out (groups, 512) f32; workspace: ceil(groups * rows_per_group / 128) * 2 * 512 floats.
+extern "C" int fp_linear_layernorm_mean_fwd(const void* x16, const void* w16, const float* bias, const float* x32, const float* gamma,
+                                            const float* beta, float eps, float* out, float* workspace, size_t workspace_bytes,
+                                            int groups, int rows_per_group, int K, int D, void* stream) {
+  FP_REQUIRE(groups >= 0, "fp_linear_layernorm_mean_fwd: groups < 0");
+  if (groups == 0) return FP_OK;
+  FP_REQUIRE(x16 && w16 && x32 && gamma && beta && out && workspace, "fp_linear_layernorm_mean_fwd: NULL tensor");
+  FP_REQUIRE(D == 512 && K > 0 && K % LL_BK == 0, "fp_linear_layernorm_mean_fwd: D must be 512, K a multiple of %d", LL_BK);
+  FP_REQUIRE(rows_per_group >= 128, "fp_linear_layernorm_mean_fwd: a tile of 128 rows may touch two groups at most");
+  const long long M = (long long)groups * rows_per_group;
+  FP_REQUIRE(M * K < (1ll << 30), "fp_linear_layernorm_mean_fwd: operands exceed 2 GiB");
+  const int tiles = fp_cdiv((int)M, 128);
+  FP_REQUIRE(workspace_bytes >= (size_t)tiles * 2 * 512 * sizeof(float), "fp_linear_layernorm_mean_fwd: workspace too small");
+  LinearLnParams p;
+  p.X = (const _Float16*)x16; p.Wt = (const _Float16*)w16; p.bias = bias; p.x32 = x32; p.tok16 = nullptr; p.pe = nullptr;
+  p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M; p.K = K;
+  p.part = workspace;
+  constexpr int LDS = LlTile<128, 3>::LDS;
+  FP_SET_MAX_LDS((k_linear_ln512<128, 3, true>), LDS);
+  hipLaunchKernelGGL((k_linear_ln512<128, 3, true>), dim3(tiles), dim3(LL_THREADS), LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(k_ln_mean_finish, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, gamma, beta, out,
+                     rows_per_group, 128);
+  FP_CHECK_LAUNCH("fp_linear_layernorm_mean_fwd");
+  return FP_OK;
+}
+#endif
 
 extern "C" int fp_linear_layernorm_fwd(const void* x16, const void* w16, const float* bias, const float* x32, const void* tok16,
                                        const float* pe, int S, const float* gamma, const float* beta, float eps, float* y32,
@@ -286,7 +378,7 @@ extern "C" int fp_linear_layernorm_fwd(const void* x16, const void* w16, const f
                (size_t)y32 | (size_t)y16) & 15) == 0, "fp_linear_layernorm_fwd: tensors must be 16-byte aligned");
   LinearLnParams p;
   p.X = (const _Float16*)x16; p.Wt = (const _Float16*)w16; p.bias = bias; p.x32 = x32; p.tok16 = (const _Float16*)tok16; p.pe = pe;
-  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.K = K;
+  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.K = K; p.part = nullptr;
 #ifdef FP_PROFILE_BUILD
   // profiling build only: FP_LL_TILE=64 selects the 64-row tile with two workgroups per CU (bit-identical by construction: the
   // same k order and the same row code; scripts/bench_linear_ln.py)
