@@ -27,7 +27,6 @@ constexpr int LL_ROWB = LL_BK * 2;                       // bytes per LDS row (o
 constexpr int LL_KK = LL_BK / 16;                        // MFMA k-substeps per stage
 constexpr int LL_W_BYTES = LL_BN * LL_ROWB;              // 32 KiB
 constexpr int LL_WI = 4;                                 // W-tile LDS-DMA instructions per wave and stage (A tile: one)
-constexpr int LL_R = 4;                                  // rows a wave normalises together (interleaved reduction chains)
 template <int BM, int NST>
 struct LlTile {
   static constexpr int TM = BM / 32;
@@ -38,8 +37,10 @@ struct LlTile {
   static constexpr int LDS = MAIN + LL_BN * 4;           // + the bias vector
   static constexpr int ROWS_PER_WAVE = BM / LL_NW;
   static constexpr int WG_PER_CU = LDS <= 80 * 1024 ? 2 : 1;
+  static constexpr int R = WG_PER_CU == 2 ? 2 : 4;       // rows a wave normalises together (interleaved reduction chains); two
+                                                         // where the workgroup has 128 registers per lane
   static_assert(BM % 32 == 0 && (BM / 16) <= LL_NW && LL_NW % (BM / 16) == 0, "A tile: 16 rows per LDS-DMA instruction, one per wave");
-  static_assert(ROWS_PER_WAVE % LL_R == 0, "rows per wave must be a multiple of the LayerNorm group");
+  static_assert(ROWS_PER_WAVE % R == 0, "rows per wave must be a multiple of the LayerNorm group");
   static_assert(NST == 2 || NST == 3, "counted waits are written for 2 or 3 stages");
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
 };
@@ -73,10 +74,10 @@ __device__ __forceinline__ void ll_dma16(const __amdgpu_buffer_rsrc_t& rs, void*
 // p.S rows (the token mean of refine_network.py:90-91 fused with norm2): per-tile partial column sums, finished by
 // k_ln_mean_finish in a fixed order.
 template <int BM, int NST, bool MEAN = false>
-__global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU)) void k_linear_ln512(LinearLnParams p) {
+__global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 1)) void k_linear_ln512(LinearLnParams p) {
   using T = LlTile<BM, NST>;
   constexpr int LL_BM = BM, LL_NST = NST, LL_TM = T::TM, LL_A_BYTES = T::A_BYTES, LL_STAGE = T::STAGE, LL_MAIN = T::MAIN;
-  constexpr int LL_ROWS_PER_WAVE = T::ROWS_PER_WAVE;
+  constexpr int LL_ROWS_PER_WAVE = T::ROWS_PER_WAVE, LL_R = T::R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = channel group of 64
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU)) void k_li
       }
     }
   };
-  request_resid(0);   // in flight under the transposition below
+  // requested before the accumulators are parked (in flight under the transposition) where the registers allow it: the two-per-CU
+  // tile has 128 registers per lane, and its other workgroup covers the latency anyway
+  constexpr bool EARLY_RESID = T::WG_PER_CU == 1;
+  if constexpr (EARLY_RESID) request_resid(0);
 
   // ---- epilogue 1: f16(acc + bias) -> E[row][channel], rows of 1 KiB, the low 4 bits of the 16-byte chunk index XORed with
   // (row & 15) (igemm_epilogue.h).  D[i = channel][j = row]: a lane holds row (lane & 31) of a row tile and channels
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU)) void k_li
     }
   }
   __syncthreads();
+  if constexpr (!EARLY_RESID) request_resid(0);
 
   // ---- epilogue 2: k_layernorm_res512's row code on the tile's rows (wave w: rows w, w + 8, ...), LL_R rows at a time.
   // The residual rows of the NEXT group are requested before the current group is normalised (and those of the first group
