@@ -14,6 +14,7 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "igemm_common.h"
 #include "rowops_ln.h"
 
@@ -60,6 +61,8 @@ struct LinearLnParams {
   _Float16* y16;
   int M, K;
   float* part;            // MEAN variant (profiling build): per-tile partial column sums [tiles][2][512]; S = rows per group
+  const _Float16* W2;     // FFN variant (profiling build): second Linear (512, 512) and its bias; Wt / bias are the first (+ ReLU)
+  const float* bias2;
 };
 
 __device__ __forceinline__ int ll_swz(int row) { return (row >> 2) & 3; }   // chunk swizzle of a 64-byte row (4 rows per bank row)
@@ -73,7 +76,10 @@ __device__ __forceinline__ void ll_dma16(const __amdgpu_buffer_rsrc_t& rs, void*
 // MEAN (profiling build only, fp_linear_layernorm_mean_fwd): instead of writing the normalised rows, add them up per group of
 // p.S rows (the token mean of refine_network.py:90-91 fused with norm2): per-tile partial column sums, finished by
 // k_ln_mean_finish in a fixed order.
-template <int BM, int NST, bool MEAN = false>
+// FFN (profiling build only, fp_ffn_layernorm_mean_fwd): TWO Linears back to back on the tile, linear1 + ReLU -> the 128 x 512
+// intermediate parked in the epilogue tile -> linear2 reading its A fragments from that tile and its weights straight from L2 into
+// registers (a wave owns 64 output channels, so nobody shares its weight rows: no staging, no barrier in the second loop).
+template <int BM, int NST, bool MEAN = false, bool FFN = false>
 __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 1)) void k_linear_ln512(LinearLnParams p) {
   using T = LlTile<BM, NST>;
   constexpr int LL_BM = BM, LL_NST = NST, LL_TM = T::TM, LL_A_BYTES = T::A_BYTES, LL_STAGE = T::STAGE, LL_MAIN = T::MAIN;
@@ -207,13 +213,82 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 
   };
   // requested before the accumulators are parked (in flight under the transposition) where the registers allow it: the two-per-CU
   // tile has 128 registers per lane, and its other workgroup covers the latency anyway
-  constexpr bool EARLY_RESID = T::WG_PER_CU == 1;
+  constexpr bool EARLY_RESID = T::WG_PER_CU == 1 && !FFN;   // FFN: the second loop needs the registers
   if constexpr (EARLY_RESID) request_resid(0);
 
   // ---- epilogue 1: f16(acc + bias) -> E[row][channel], rows of 1 KiB, the low 4 bits of the 16-byte chunk index XORed with
   // (row & 15) (igemm_epilogue.h).  D[i = channel][j = row]: a lane holds row (lane & 31) of a row tile and channels
   // 8 g + 4 (lane >> 5) + {0..3} of a channel tile, g = register >> 2
   unsigned char* E = smem;
+  if constexpr (FFN) {
+    // ---- linear1 done: H = relu(f16(acc + b1)) -> E, then linear2 out of E
+    {
+    #pragma unroll
+      for (int i = 0; i < 2; ++i) {
+    #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wid * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
+          const float4_ bv = *reinterpret_cast<const float4_*>(bias_lds + nl);
+    #pragma unroll
+          for (int j = 0; j < LL_TM; ++j) {
+            const int ml = j * 32 + (lane & 31);
+            half4 v;
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
+            v = __builtin_elementwise_max(v, half4{0, 0, 0, 0});                   // ReLU of linear1
+            const int chunk = (nl >> 3) ^ (ml & 15);
+            *reinterpret_cast<half4*>(E + ml * (2 * LL_BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();                 // H complete; nobody reads b1 any more
+    if (wid < 2) {                   // b2 -> the bias area (visible after the barrier that ends the second loop)
+      float* dst = bias_lds + wid * 256;
+      if (p.bias2) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias2), 0, LL_BN * 4, 0x00020000);
+        ll_dma16(rs, dst, lane * 16, wid * 1024);
+      } else {
+        *reinterpret_cast<float4_*>(dst + lane * 4) = float4_{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < LL_TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // W2 fragment of k16-step q for channel tile i: 8 consecutive k of row (output channel) 64 wid + 32 i + (lane & 31),
+    // starting at 16 q + 8 (lane >> 5): one 16-byte load per lane, RING steps ahead
+    constexpr int NQ = LL_BN / 16, RING = 4;
+    const _Float16* w2p = p.W2 + (size_t)(wid * 64 + frow) * LL_BN + fhalf * 8;
+    half8 wr[RING][2];
+    auto wload = [&](int q, int slot) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wr[slot][i] = *reinterpret_cast<const half8*>(w2p + (size_t)i * 32 * LL_BN + q * 16);
+    };
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) wload(q, q);
+    // A fragment of k16-step q, row tile j: row 32 j + (lane & 31) of E, logical chunk 2 q + (lane >> 5)
+    const unsigned char* erow = E + frow * (2 * LL_BN);
+    const int esw = frow & 15;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q + RING - 1 < NQ) wload(q + RING - 1, (q + RING - 1) % RING);
+      half8 fa2[LL_TM];
+#pragma unroll
+      for (int j = 0; j < LL_TM; ++j)
+        fa2[j] = *reinterpret_cast<const half8*>(erow + j * 32 * (2 * LL_BN) + (((2 * q + fhalf) ^ esw) << 4));
+      __builtin_amdgcn_sched_barrier(0);   // keep the weight loads RING - 1 steps ahead (hipcc otherwise sinks them to their use)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < LL_TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[q % RING][i], fa2[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // b2 has landed (waves 0, 1)
+    __syncthreads();                 // every wave is done reading H before linear2's output takes its place
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -357,13 +432,42 @@ extern "C" int fp_linear_layernorm_mean_fwd(const void* x16, const void* w16, co
   LinearLnParams p;
   p.X = (const _Float16*)x16; p.Wt = (const _Float16*)w16; p.bias = bias; p.x32 = x32; p.tok16 = nullptr; p.pe = nullptr;
   p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M; p.K = K;
-  p.part = workspace;
+  p.part = workspace; p.W2 = nullptr; p.bias2 = nullptr;
   constexpr int LDS = LlTile<128, 3>::LDS;
   FP_SET_MAX_LDS((k_linear_ln512<128, 3, true>), LDS);
   hipLaunchKernelGGL((k_linear_ln512<128, 3, true>), dim3(tiles), dim3(LL_THREADS), LDS, (hipStream_t)stream, p);
   hipLaunchKernelGGL(k_ln_mean_finish, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, gamma, beta, out,
                      rows_per_group, 128);
   FP_CHECK_LAUNCH("fp_linear_layernorm_mean_fwd");
+  return FP_OK;
+}
+
+// Profiling build only (scripts/bench_linear_ln_mean.py): the whole feed-forward half of the refiner's encoder layer in one launch
+// + the finish kernel -- linear1 + ReLU + linear2 + residual + norm2 + token mean (refine_network.py:56-70, :90-91); = two
+// fp_igemm_f16_fwd + fp_colmean_f16_fwd with the (M, 512) intermediates staying in LDS.  Both Linears are 512 -> 512.
+extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1, const float* b1, const void* w2, const float* b2,
+                                         const float* x32, const float* gamma, const float* beta, float eps, float* out,
+                                         float* workspace, size_t workspace_bytes, int groups, int rows_per_group, void* stream) {
+  FP_REQUIRE(groups >= 0, "fp_ffn_layernorm_mean_fwd: groups < 0");
+  if (groups == 0) return FP_OK;
+  FP_REQUIRE(y16 && w1 && w2 && x32 && gamma && beta && out && workspace, "fp_ffn_layernorm_mean_fwd: NULL tensor");
+  FP_REQUIRE(rows_per_group >= 128, "fp_ffn_layernorm_mean_fwd: a tile of 128 rows may touch two groups at most");
+  const long long M = (long long)groups * rows_per_group;
+  FP_REQUIRE(M * 512 < (1ll << 30), "fp_ffn_layernorm_mean_fwd: operands exceed 2 GiB");
+  FP_REQUIRE((((size_t)y16 | (size_t)w1 | (size_t)w2 | (size_t)b1 | (size_t)b2 | (size_t)x32 | (size_t)gamma | (size_t)beta) & 15) == 0,
+             "fp_ffn_layernorm_mean_fwd: tensors must be 16-byte aligned");
+  const int tiles = fp_cdiv((int)M, 128);
+  FP_REQUIRE(workspace_bytes >= (size_t)tiles * 2 * 512 * sizeof(float), "fp_ffn_layernorm_mean_fwd: workspace too small");
+  LinearLnParams p;
+  p.X = (const _Float16*)y16; p.Wt = (const _Float16*)w1; p.bias = b1; p.x32 = x32; p.tok16 = nullptr; p.pe = nullptr;
+  p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M; p.K = 512;
+  p.part = workspace; p.W2 = (const _Float16*)w2; p.bias2 = b2;
+  constexpr int LDS = LlTile<128, 3>::LDS;
+  FP_SET_MAX_LDS((k_linear_ln512<128, 3, true, true>), LDS);
+  hipLaunchKernelGGL((k_linear_ln512<128, 3, true, true>), dim3(tiles), dim3(LL_THREADS), LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(k_ln_mean_finish, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, gamma, beta, out,
+                     rows_per_group, 128);
+  FP_CHECK_LAUNCH("fp_ffn_layernorm_mean_fwd");
   return FP_OK;
 }
 #endif
@@ -383,7 +487,7 @@ extern "C" int fp_linear_layernorm_fwd(const void* x16, const void* w16, const f
                (size_t)y32 | (size_t)y16) & 15) == 0, "fp_linear_layernorm_fwd: tensors must be 16-byte aligned");
   LinearLnParams p;
   p.X = (const _Float16*)x16; p.Wt = (const _Float16*)w16; p.bias = bias; p.x32 = x32; p.tok16 = (const _Float16*)tok16; p.pe = pe;
-  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.K = K; p.part = nullptr;
+  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.K = K; p.part = nullptr; p.W2 = nullptr; p.bias2 = nullptr;
 #ifdef FP_PROFILE_BUILD
   // profiling build only: FP_LL_TILE=64 selects the 64-row tile with two workgroups per CU (bit-identical by construction: the
   // same k order and the same row code; scripts/bench_linear_ln.py)

@@ -1,5 +1,7 @@
-"""linear2 + residual + norm2 + token mean of the refiner's encoder layer in one launch + a finish kernel (profiling build only:
-fp_linear_layernorm_mean_fwd in csrc/linear_ln.hip) against the product path fp_igemm_f16_fwd + fp_colmean_f16_fwd:
+"""The feed-forward half of the refiner's encoder layer on the fused 128 x 512 tile (profiling build only, csrc/linear_ln.hip):
+  fp_linear_layernorm_mean_fwd : linear2 + residual + norm2 + token mean            (product: fp_igemm_f16_fwd + fp_colmean_f16_fwd)
+  fp_ffn_layernorm_mean_fwd    : linear1 + ReLU + linear2 + residual + norm2 + mean (product: 2 x fp_igemm_f16_fwd + fp_colmean_f16_fwd)
+each one launch + a finish kernel:
     make -C foundationpose_amd/csrc profile
     FP_AMD_LIB=foundationpose_amd/csrc/libfp_amd_profile.so python scripts/bench_linear_ln_mean.py
 Prints the largest deviation (the token mean is summed in another, fixed, order: per-tile partial sums, so the results are not
@@ -19,8 +21,12 @@ fn = L.fp_linear_layernorm_mean_fwd          # AttributeError with the product l
 fn.restype = C.c_int
 vp = C.c_void_p
 fn.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+ffn = L.fp_ffn_layernorm_mean_fwd
+ffn.restype = C.c_int
+ffn.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
 g = torch.Generator(device="cpu").manual_seed(4)
 lin = _HipLinear((torch.randn((512, 512), generator=g) * 0.05).to(dev), (torch.randn((512,), generator=g) * 0.1).to(dev))
+lin1 = _HipLinear((torch.randn((512, 512), generator=g) * 0.05).to(dev), (torch.randn((512,), generator=g) * 0.1).to(dev))
 gamma = (1.0 + 0.1 * torch.randn((512,), generator=g)).to(dev)
 beta = (0.1 * torch.randn((512,), generator=g)).to(dev)
 
@@ -56,3 +62,16 @@ for n, S in ((126, 400), (252, 400), (3, 400), (2, 130)):
     d = (a - b).abs()
     print(f"N={n} S={S}: max |diff| {float(d.max()):.3e} (values up to {float(a.abs().max()):.3f}), "
           f"linear + colmean {timed(two):.1f} us, fused + finish {timed(fused):.1f} us")
+
+    out2 = torch.empty_like(out)
+
+    def fused_ffn():
+        st = ffn(x.data_ptr(), lin1.w.data_ptr(), lin1.b.data_ptr(), lin.w.data_ptr(), lin.b.data_ptr(), y32.data_ptr(), gamma.data_ptr(),
+                 beta.data_ptr(), 1e-5, out2.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, S, torch.cuda.current_stream().cuda_stream)
+        assert st == 0, L.fp_last_error()
+        return out2
+
+    three = lambda: ops.colmean_f16(lin(lin1(x, relu=True)), gamma, beta, 1e-5, resid32=y32)
+    a, b = three().clone(), fused_ffn().clone()
+    d = (a - b).abs()
+    print(f"          FFN: max |diff| {float(d.max()):.3e}, linear1 + linear2 + colmean {timed(three):.1f} us, fused + finish {timed(fused_ffn):.1f} us")
