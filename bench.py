@@ -40,18 +40,20 @@ SCORE_GFLOP_CROSS_252 = 0.659
 STEM_GFLOP_PER_IMAGE = (80 * 80 * 64 * 6 * 49 + 40 * 40 * 128 * 64 * 9 + 4 * 40 * 40 * 128 * 128 * 9) * 2 / 1e9   # encodeA, one 160x160 image
 # roofline that bounds each hand-written kernel (DESIGN.md "Kernels")
 KERNEL_BOUND = {"fp_render_crops": "hbm", "fp_warp_crops": "hbm", "fp_conv7x7s2_bn_relu_fwd": "hbm",
-                "fp_igemm_f16_fwd": "mfma", "fp_linear_layernorm_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
+                "fp_igemm_f16_fwd": "mfma", "fp_linear_layernorm_fwd": "mfma", "fp_ffn_layernorm_mean_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
                 "fp_colmean_f16_fwd": "hbm", "fp_attention_f16_fwd": "mfma"}
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    scripts/pmc_traffic.py with the gfx950 FETCH_SIZE x2 correction); None when that kernel was not profiled."""
+    """-> (HBM bytes per launch, launches it averages, {rocprof kernel name: launches}) from the committed rocprofv3 PMC passes
+    over one step of `bench.py --serialize` (profiles/traffic.json, written by scripts/pmc_step_traffic.py with the gfx950
+    FETCH_SIZE x2 correction): the mean over THE launches `avg_launch_ms` averages; (None, 0, {}) when not profiled."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, 0, {}
     with open(path) as f:
-        return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+        ent = json.load(f).get(kernel, {})
+    return ent.get("hbm_bytes_per_launch"), ent.get("launches", 0), {k: v.get("launches") for k, v in ent.get("kernels", {}).items()}
 
 
 def build_scene(dev, seed, n_hyp):
@@ -248,6 +250,8 @@ def main():
                     "estimater.register() does: the observed crop of the first iteration is then warped and stem-encoded once per "
                     "sub-batch instead of once per hypothesis (bit-identical result).  Off by default: the headline runs every "
                     "hypothesis's full arithmetic")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region instead of hipGraph replays of the "
+                    "refine loop and of the scorer's per-hypothesis half (PoseRefinePredictor / ScorePredictor graph=False)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (instrumented) pass")
     args = ap.parse_args()
@@ -286,7 +290,8 @@ def main():
     hyp_mode = args.mode == "hypothesis"
     _log("building scene")
     sc = build_scene(dev, seed=0 if hyp_mode else rank, n_hyp=N)   # hypothesis mode: every rank sees the same object
-    opts = dict(device=dev, precision=args.precision, n_streams=args.streams)
+    # graph=True: captured at the first (warm-up) call of a key; the passes under ops.KernelTimers launch eagerly by themselves
+    opts = dict(device=dev, precision=args.precision, n_streams=args.streams, graph=not args.no_graph)
     refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), **opts)
     scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), **opts)
     rgb_t = torch.as_tensor(sc["rgb"], device=dev).float().contiguous()
@@ -406,6 +411,9 @@ def main():
                                    f"{N} hypotheses, {R} refine iterations + 1 score pass, 160x160 crops, random-init weights",
                        "hypotheses_per_gpu": (N + world - 1) // world if hyp_mode else N, "refine_iterations": R,
                        "shared_observed_crop_in_iteration_0": bool(args.shared_crop and args.precision == "fp16"),
+                       "launch_mode": ("eager launches" if (args.no_graph or args.precision != "fp16") else
+                                       "hipGraph replay: one linear graph per sub-batch for the 5-iteration refine loop and one for the "
+                                       "scorer's per-hypothesis half, bit-identical to the eager launches"),
                        "network": {"fp16": "libfp_amd.so (hand-written MFMA kernels)", "torch_amp": "PyTorch-ROCm under torch.autocast "
                                    "(MIOpen / rocBLAS / ATen)", "fp32": "PyTorch-ROCm fp32"}[args.precision],
                        "parallelism": ("single GPU, no collective (torch.distributed not initialised)" if not use_dist else
@@ -446,12 +454,15 @@ def main():
                 ach, peak, unit = dk["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
             r_ms, w_ms = ksum["fp_render_crops"]["avg_ms"], ksum["fp_warp_crops"]["avg_ms"]
             stage_bytes = ksum["fp_render_crops"]["bytes"] + ksum["fp_warp_crops"]["bytes"]
-            out["roofline"] = {"kernel": dom, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                               "traffic": measured_traffic(dom),
-                               "traffic_note": "HBM-side bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, profiles/) of "
-                                               "ONE representative launch of this kernel: the 256->256 3x3 conv at N=252 "
-                                               "(algorithmic 228 MB read + 206 MB written); achieved/avg_launch_ms average all "
-                                               "launches of the step" if dom == "fp_igemm_f16_fwd" else "profiles/traffic.json",
+            traffic, traffic_n, traffic_kernels = measured_traffic(dom)
+            out["roofline"] = {"kernel": dom, "rocprof_kernels": traffic_kernels, "bound": bound, "achieved": ach, "peak": peak,
+                               "unit": unit, "frac": ach / peak, "traffic": traffic,
+                               "traffic_note": f"HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes), mean "
+                                               f"over the {traffic_n} launches of this entry point in ONE step of `bench.py --serialize` -- the "
+                                               f"launches (kernels, sub-batch sizes, one stream) that achieved / avg_launch_ms average; "
+                                               f"algorithmic HBM bytes of the same launches: algorithmic_bytes_per_launch "
+                                               f"(scripts/pmc_step_traffic.py -> profiles/traffic.json)",
+                               "algorithmic_bytes_per_launch": dk["bytes"],
                                "algorithmic_per_launch": dk["bytes"] if bound == "hbm" else dk["flops"],
                                "avg_launch_ms": dk["avg_ms"], "launches_timed": dk["calls"]}
             if timers_full.records:

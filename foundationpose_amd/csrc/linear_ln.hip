@@ -385,7 +385,6 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 
   }
 }
 
-#ifdef FP_PROFILE_BUILD
 // out[g][c] = mean over the rows of group g of LN(...) * gamma + beta from the tiles' partial sums, tiles in increasing order
 __global__ __launch_bounds__(512) void k_ln_mean_finish(const float* __restrict__ part, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ out, int S, int BM) {
@@ -399,7 +398,6 @@ __global__ __launch_bounds__(512) void k_ln_mean_finish(const float* __restrict_
   a *= 1.0f / (float)S;
   out[(size_t)g * 512 + c] = fmaf(a, gamma[c], beta[c]);   // mean(LN(x) * gamma + beta) = mean(LN(x)) * gamma + beta
 }
-#endif
 
 template <int BM, int NST>
 int ll_launch(const LinearLnParams& p, hipStream_t stream) {
@@ -441,10 +439,11 @@ extern "C" int fp_linear_layernorm_mean_fwd(const void* x16, const void* w16, co
   FP_CHECK_LAUNCH("fp_linear_layernorm_mean_fwd");
   return FP_OK;
 }
+#endif
 
-// Profiling build only (scripts/bench_linear_ln_mean.py): the whole feed-forward half of the refiner's encoder layer in one launch
-// + the finish kernel -- linear1 + ReLU + linear2 + residual + norm2 + token mean (refine_network.py:56-70, :90-91); = two
-// fp_igemm_f16_fwd + fp_colmean_f16_fwd with the (M, 512) intermediates staying in LDS.  Both Linears are 512 -> 512.
+// The whole feed-forward half of the refiner's encoder layer in one launch + the finish kernel -- linear1 + ReLU + linear2 +
+// residual + norm2 + token mean (refine_network.py:56-70, :90-91); = two fp_igemm_f16_fwd + fp_colmean_f16_fwd with the (M, 512)
+// intermediates staying in LDS.  Both Linears are 512 -> 512.  include/fp_amd.h.
 extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1, const float* b1, const void* w2, const float* b2,
                                          const float* x32, const float* gamma, const float* beta, float eps, float* out,
                                          float* workspace, size_t workspace_bytes, int groups, int rows_per_group, void* stream) {
@@ -470,7 +469,6 @@ extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1, const 
   FP_CHECK_LAUNCH("fp_ffn_layernorm_mean_fwd");
   return FP_OK;
 }
-#endif
 
 extern "C" int fp_linear_layernorm_fwd(const void* x16, const void* w16, const float* bias, const float* x32, const void* tok16,
                                        const float* pe, int S, const float* gamma, const float* beta, float eps, float* y32,

@@ -16,6 +16,68 @@ from . import ops
 from .Utils import get_mesh_handle
 
 
+class PartGraphs:
+    """k LINEAR hipGraphs, one per hypothesis sub-batch of a predictor (overlap.py), replayed on the sub-batch streams:
+    forked from / joined into the caller's stream, so the overlap between sub-batches is ordinary stream semantics and every
+    graph stays a simple chain.  `body(h)` issues part h's whole launch sequence on the CURRENT stream; everything it
+    addresses by raw pointer has to outlive the graphs (static inputs / outputs owned by the caller; tensors allocated inside
+    the capture live in the graph's private pool)."""
+
+    def __init__(self, sub, dev, n_parts, body, warmup=2):
+        self.sub, self.dev, self.n = sub, dev, n_parts
+        # eager warm-up runs on a side stream (lazy one-time initialisation inside the library and in PyTorch), then the
+        # captures, one after the other
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                for h in range(n_parts):
+                    body(h)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.graphs = []
+        for h in range(n_parts):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body(h)
+            self.graphs.append(g)
+
+    def replay(self):
+        streams = self.sub.streams(self.dev, self.n)
+        self.sub.fork(streams)
+        for h, g in enumerate(self.graphs):
+            with torch.cuda.stream(streams[h]):
+                g.replay()
+        self.sub.join(streams)
+
+
+class GraphCache:
+    """what `graph="auto"` of the predictors means: a (shape, intrinsics, mesh, ...) key is captured the SECOND time it is
+    seen -- a single call (a test, one register()) stays eager, a loop over frames or objects of one shape replays graphs from
+    its third pass on -- and at most `cap` captured keys are kept (least recently used first out; a capture owns a private
+    memory pool)."""
+
+    def __init__(self, cap=4):
+        self.cap, self.seen, self.items = cap, {}, {}
+
+    def get(self, key, mode, build):
+        """mode True: capture now; 'auto': on the second sighting; -> the captured object or None (= run eagerly)"""
+        it = self.items.pop(key, None)
+        if it is not None:
+            self.items[key] = it          # most recently used last
+            return it
+        n = self.seen[key] = self.seen.get(key, 0) + 1
+        if len(self.seen) > 64:
+            self.seen = {key: n}
+        if mode is True or (mode == "auto" and n >= 2):
+            it = build()
+            self.items[key] = it
+            while len(self.items) > self.cap:
+                self.items.pop(next(iter(self.items)))
+            return it
+        return None
+
+
 class GraphedTracker:
     """Static-shape tracker: `step(rgb, depth[, poses])` -> refined poses (N,4,4) on the device (a static buffer, valid
     until the next call).  With `poses=None` the previous output is the next input (tracking).

@@ -127,6 +127,7 @@ def crop_windows(poses, K, mesh_diameter, crop_ratio, out_size=(160, 160)):
 
 
 _WS = {}
+_WS_IN_GRAPHS = []
 
 
 def workspace_bytes(N, V, T, oh=160, ow=160):
@@ -137,14 +138,18 @@ def _workspace(nbytes, device):
     """library-side default scratch: one per (device, stream) -- launches on different streams may overlap"""
     if nbytes == 0:
         return None
-    if torch.cuda.is_current_stream_capturing():
-        # an allocation made here would come from the capturing graph's private pool and then be cached process-wide
-        raise _lib.FpAmdError("render_crops inside a stream capture needs a caller-owned `workspace` (ops.workspace_bytes)")
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ws is None or ws.numel() < nbytes:
+        if capturing:
+            # an allocation made here would come from the capturing graph's private pool and then be cached process-wide
+            raise _lib.FpAmdError("render_crops inside a stream capture needs a caller-owned `workspace` (ops.workspace_bytes) "
+                                  "or a default scratch that is already large enough")
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _WS[key] = ws
+    elif capturing:
+        _WS_IN_GRAPHS.append(ws)      # a graph now holds its address: kept alive even if a larger scratch replaces it later
     return ws
 
 
@@ -384,6 +389,26 @@ def linear_layernorm_res(x16, w16, bias, gamma, beta, eps=1e-5, x32=None, tok16=
     return y32, y16
 
 
+def ffn_layernorm_mean(y16, w1, b1, w2, b2, x32, gamma, beta, eps=1e-5):
+    """(G, R, 512) fp16 y16 (norm1's output) + (G, R, 512) f32 residual stream -> (G, 512) f32 =
+    mean_r LN(x32 + linear2(relu(linear1(y16)))) * gamma + beta, one launch + a finish kernel (fp_ffn_layernorm_mean_fwd):
+    the feed-forward half of the encoder layer and the token mean with both (G*R, 512) intermediates staying on chip"""
+    y = _dev(y16, torch.float16, "y16")
+    G_, R, D = (int(v) for v in y.shape)
+    if D != 512:
+        raise _lib.FpAmdError("ffn_layernorm_mean: d_model must be 512")
+    x32 = _dev(x32, torch.float32, "x32")
+    out = torch.empty((G_, D), dtype=torch.float32, device=y.device)
+    tiles = (G_ * R + 127) // 128
+    ws = torch.empty((max(tiles, 1), 2, 512), dtype=torch.float32, device=y.device)
+    st = _lib.lib().fp_ffn_layernorm_mean_fwd(_ptr(y), _ptr(_dev(w1, torch.float16, "w1")), _ptr(_dev(b1, torch.float32, "b1")),
+                                              _ptr(_dev(w2, torch.float16, "w2")), _ptr(_dev(b2, torch.float32, "b2")), _ptr(x32),
+                                              _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")), float(eps),
+                                              _ptr(out), _ptr(ws), ws.numel() * 4, G_, R, _stream(y))
+    _lib.check(st, "fp_ffn_layernorm_mean_fwd")
+    return out
+
+
 def colmean_f16(x, gamma=None, beta=None, eps=1e-5, resid32=None):
     """x (G, R, 512) fp16 -> (G, 512) f32: mean over R of LN(resid32 + x)*gamma+beta (gamma given) or of x (fp_colmean_f16_fwd)"""
     x = _dev(x, torch.float16, "x")
@@ -555,6 +580,8 @@ linear_layernorm_res = _timed("fp_linear_layernorm_fwd", linear_layernorm_res,
                                                      ((4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
                                                       + (2.0 if k.get("want16", True) else 0.0)),
                                                      2.0 * x.numel() * w.shape[0]))
+ffn_layernorm_mean = _timed("fp_ffn_layernorm_mean_fwd", ffn_layernorm_mean,
+                            lambda y, w1, b1, w2, *a, **k: (6.0 * y.numel() + 2.0 * (w1.numel() + w2.numel()), 4.0 * y.numel() * 512))
 colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16,
                      lambda x, *a, **k: ((6.0 if k.get("resid32") is not None else 2.0) * x.numel(), 0.0))
 rows_linear = _timed("fp_rows_linear_fwd", rows_linear)

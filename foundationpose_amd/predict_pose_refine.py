@@ -14,6 +14,7 @@ from . import ops
 from .Utils import get_mesh_handle, make_mesh_tensors
 from .engine import RefinePlan
 from .h5_dataset import PoseRefinePairH5Dataset
+from .graphs import GraphCache, PartGraphs
 from .overlap import SubBatches
 from .pose_dataset import BatchPoseData
 from .refine_network import RefineNet
@@ -97,11 +98,17 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
 
 def resolve_shared_translation(ob_in_cams, flag):
     """-> bool: may the first refine iteration treat the hypotheses as sharing one translation (PoseRefinePredictor.predict)?
-    flag True: the caller says so (checked when the poses are host data); None: decided from host poses -- compared as the
-    float32 values that are uploaded -- and False for a device tensor, which is never read back; False: no."""
+    flag True: the caller says so -- and is checked: host poses on the host, a device tensor with one reduction on the device
+    (one scalar read back; skipped only inside a stream capture, where nothing may synchronise); None: decided from host poses
+    -- compared as the float32 values that are uploaded -- and False for a device tensor, which is not read back for a mere
+    optimisation; False: no."""
     on_host = isinstance(ob_in_cams, np.ndarray) or (torch.is_tensor(ob_in_cams) and ob_in_cams.device.type == "cpu") or \
         isinstance(ob_in_cams, (list, tuple))
     if not on_host:
+        if flag and torch.is_tensor(ob_in_cams) and ob_in_cams.is_cuda and not torch.cuda.is_current_stream_capturing():
+            t = ob_in_cams.reshape(-1, 4, 4)[:, :3, 3].float()
+            if t.shape[0] > 1 and not bool((t == t[:1]).all().item()):
+                raise ValueError("shared_translation=True, but the hypotheses do not have one translation")
         return bool(flag)
     t = np.asarray(ob_in_cams, dtype=np.float32).reshape(-1, 4, 4)[:, :3, 3]
     same = bool(t.shape[0] > 1 and (t == t[:1]).all())
@@ -114,11 +121,15 @@ class PoseRefinePredictor:
     run_name = "2023-10-28-18-33-37"
 
     def __init__(self, cfg=None, state_dict=None, weights_root=None, device="cuda", precision="fp16", channels_last=True,
-                 n_streams=2):
+                 n_streams=2, graph="auto"):
         """precision='fp16': the reference's deployed autocast configuration on libfp_amd.so (engine.py);
         'fp32': fp32 torch ops, no autocast (`amp=False` in the reference).  n_streams: hypothesis sub-batches that run
-        concurrently (overlap.py); 1 = one launch sequence over the whole batch"""
+        concurrently (overlap.py); 1 = one launch sequence over the whole batch.  graph: hipGraph replay of predict()'s refine
+        loop (fp16 plan only): True = capture at the first call of a (shape, intrinsics, mesh, iteration) key, "auto" = at the
+        second (graphs.GraphCache), False = always eager launches; per call: predict(graph=...)"""
         self.sub = SubBatches(n_streams)
+        self.graph = graph
+        self._graphs = GraphCache()
         self.amp = precision != "fp32"
         if cfg is None or state_dict is None:
             cfg, state_dict, ckpt_dir = load_run(self.run_name, weights_root)
@@ -240,6 +251,45 @@ class PoseRefinePredictor:
         self._raw_parts = [None if st is None else st["raw"] for st in state]   # last_raw_output
         return outs[:3]
 
+    def refine_graphed(self, rgb_t, xyz_t, poses, K, H, W, mesh_tensors, mesh_diameter, iteration, shared_translation, mode):
+        """refine_device as a replay of hipGraphs: ONE linear graph per hypothesis sub-batch holding its whole `iteration`-deep
+        launch sequence (~90 launches per iteration), replayed on the sub-batch streams (graphs.PartGraphs) -- the same kernels
+        on the same streams in the same order, so the result is bit-identical to the eager loop
+        (tests/test_gpu_parity.py::test_graphed_predict_is_the_eager_predict).  Everything a launch addresses by raw pointer is
+        static and owned by the cache entry: copies of the frame (rgb, xyz_map) and of the start poses, the outputs, one
+        rasteriser scratch per part; intermediates live in the graphs' private pools, activations in the plan (never dropped).
+        -> (poses, trans_delta, rot_delta) as fresh tensors, or None when this call is to run eagerly (`mode`, GraphCache)"""
+        plan = self.plan()
+        if not plan.hip or iteration <= 0 or mode is False or mode is None or torch.cuda.is_current_stream_capturing() \
+                or ops.KernelTimers.active is not None:
+            return None
+        dev, N = poses.device, int(poses.shape[0])
+        handle = get_mesh_handle(mesh_tensors)
+        parts = tuple(self.sub.parts(N, dev))
+        key = (N, int(iteration), H, W, np.asarray(K, dtype=np.float64).tobytes(), id(handle), float(mesh_diameter),
+               bool(shared_translation), parts, bool(self.sub.serial), dev.index)
+
+        def build():
+            oh, ow, _, _ = self._loop_constants()
+            g = dict(rgb=torch.empty_like(rgb_t), xyz=torch.empty_like(xyz_t), poses=torch.empty_like(poses), mesh=mesh_tensors,
+                     outs=self.alloc_outputs(N, dev) + (int(iteration),), state=[None] * len(parts),
+                     ws=[torch.empty(max(16, ops.workspace_bytes(b - a, handle.V, handle.T, oh, ow)), dtype=torch.uint8, device=dev)
+                         for a, b in parts])
+            g["rgb"].copy_(rgb_t); g["xyz"].copy_(xyz_t); g["poses"].copy_(poses)
+
+            def body(h):
+                g["state"][h] = self.refine_part(h, parts[h], g["rgb"], g["xyz"], g["poses"], K, H, W, handle, mesh_diameter,
+                                                 range(int(iteration)), g["outs"], g["ws"][h], None, shared_translation=shared_translation)
+            g["graphs"] = PartGraphs(self.sub, dev, len(parts), body)
+            return g
+        g = self._graphs.get(key, mode, build)
+        if g is None:
+            return None
+        g["rgb"].copy_(rgb_t); g["xyz"].copy_(xyz_t); g["poses"].copy_(poses)
+        g["graphs"].replay()
+        self._raw_parts = [st["raw"] for st in g["state"]]      # tensors of the graphs' pools, refreshed by every replay
+        return tuple(t.clone() for t in g["outs"][:3])
+
     @staticmethod
     def alloc_outputs(N, dev):
         return (torch.empty((N, 4, 4), dtype=torch.float32, device=dev), torch.empty((N, 3), dtype=torch.float32, device=dev),
@@ -254,11 +304,13 @@ class PoseRefinePredictor:
 
     @torch.inference_mode()
     def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None,
-                mesh_tensors=None, glctx=None, mesh_diameter=None, iteration=5, shared_translation=None):
+                mesh_tensors=None, glctx=None, mesh_diameter=None, iteration=5, shared_translation=None, graph=None):
         """@rgb (H,W,3) uint8/float np or tensor; @ob_in_cams (N,4,4) np or tensor.  -> ((N,4,4) f32 device tensor, vis).
         shared_translation (not in the reference's signature): True = the caller guarantees that all hypotheses have the
         same translation (register()); None = found out here when ob_in_cams is host data (a device tensor is not read
-        back: treated as False); False = never share.  It only removes repeated work (refine_part), never changes a bit."""
+        back: treated as False); False = never share.  It only removes repeated work (refine_part), never changes a bit.
+        graph (not in the reference's signature either): None = the predictor's setting (constructor), else True / "auto" /
+        False as there -- hipGraph replay of the loop (refine_graphed), bit-identical to the eager launches."""
         self.plan()
         dev = self._plan_dev
         shared_translation = resolve_shared_translation(ob_in_cams, shared_translation)
@@ -268,8 +320,11 @@ class PoseRefinePredictor:
         rgb_t = torch.as_tensor(rgb, device=dev).to(torch.float).contiguous()
         xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
         H, W = int(rgb_t.shape[0]), int(rgb_t.shape[1])
-        B_in_cams, trans, rot = self.refine_device(rgb_t, xyz_t, B_in_cams, K, H, W, get_mesh_handle(mesh_tensors),
-                                                   mesh_diameter, iteration, shared_translation=bool(shared_translation))
+        done = self.refine_graphed(rgb_t, xyz_t, B_in_cams, K, H, W, mesh_tensors, mesh_diameter, int(iteration),
+                                   bool(shared_translation), self.graph if graph is None else graph)
+        B_in_cams, trans, rot = done if done is not None else \
+            self.refine_device(rgb_t, xyz_t, B_in_cams, K, H, W, get_mesh_handle(mesh_tensors), mesh_diameter, iteration,
+                               shared_translation=bool(shared_translation))
         self.last_trans_update = trans
         self.last_rot_update = rot
         if get_vis:

@@ -8,6 +8,7 @@ from .Utils import get_mesh_handle, make_mesh_tensors
 from .engine import ScorePlan
 from .h5_dataset import ScoreMultiPairH5Dataset
 from .pose_dataset import BatchPoseData
+from .graphs import GraphCache, PartGraphs
 from .overlap import SubBatches
 from .predict_pose_refine import _Cfg, load_run
 from .score_network import ScoreNetMultiPair
@@ -16,10 +17,11 @@ _SCORE_DEFAULTS = dict(use_normal=False, use_BN=False, zfar=np.inf, c_in=4, norm
 
 
 def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_ratio, normal_map=None, mesh_diameter=None,
-                         glctx=None, mesh_tensors=None, dataset=None, cfg=None, AB=None):
+                         glctx=None, mesh_tensors=None, dataset=None, cfg=None, AB=None, workspace=None):
     """Reference: predict_score.py:56-114 + TripletH5Dataset.transform_depth_to_xyzmap (h5_dataset.py:137-170).
     The observed xyz is rebuilt from the depth crop through the frame (3 nearest-neighbour hops) inside one kernel
-    instead of two (N,480,640[,3]) intermediates (~1.2 GB at N=252)."""
+    instead of two (N,480,640[,3]) intermediates (~1.2 GB at N=252).  AB: optional (2N,6,h,w) destination; workspace: optional
+    caller-owned rasteriser scratch (ops.workspace_bytes) -- a captured hipGraph owns its scratch."""
     H, W = depth.shape[:2]
     handle = get_mesh_handle(mesh_tensors)
     poseA = torch.as_tensor(ob_in_cams, dtype=torch.float, device=handle.device).reshape(-1, 4, 4).contiguous()
@@ -32,7 +34,7 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
     for b in range(0, N, 4096):
         e = min(N, b + 4096)
         ops.render_crops(handle, poseA[b:e], bbox2d[b:e], K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter,
-                         xyz_thr=0.1, normalize_xyz=normalize, A_out=AB[b:e])
+                         xyz_thr=0.1, normalize_xyz=normalize, A_out=AB[b:e], workspace=workspace)
         ops.warp_crops(rgb, None, depth, tf_to_crops[b:e], K, poseA[b:e], mesh_diameter, ops.MODE_SCORE,
                        normalize_xyz=normalize, out_hw=(oh, ow), B_out=AB[N + b:N + e])
     Ks = torch.as_tensor(np.asarray(K, dtype=np.float64), dtype=torch.float, device=handle.device).reshape(1, 3, 3).expand(N, 3, 3)
@@ -49,8 +51,10 @@ class ScorePredictor:
     run_name = "2024-01-11-20-02-45"
 
     def __init__(self, amp=True, cfg=None, state_dict=None, weights_root=None, device="cuda", precision=None,
-                 channels_last=True, n_streams=2):
+                 channels_last=True, n_streams=2, graph="auto"):
         self.sub = SubBatches(n_streams)      # hypothesis sub-batches that run concurrently (overlap.py); 1 = none
+        self.graph = graph                    # hipGraph replay of predict(): True / "auto" / False as PoseRefinePredictor
+        self._graphs = GraphCache()
         if precision is None:
             precision = "fp16" if amp else "fp32"
         self.amp = precision != "fp32"
@@ -85,10 +89,49 @@ class ScorePredictor:
         return self._plan
 
     @torch.inference_mode()
+    def _graphed_features(self, rgb_t, depth_t, K, poses, mesh, mesh_tensors, mesh_diameter, glctx, mode):
+        """the per-hypothesis half of predict() (crops + encoder + self-attention + pooling) as ONE linear hipGraph per
+        sub-batch, replayed on the sub-batch streams (graphs.PartGraphs): -> the static (N, 512) feature buffer, or None when
+        this call is to run eagerly.  Bit-identical to the eager launches (tests/test_gpu_parity.py)."""
+        plan = self.plan()
+        if not plan.hip or mode is False or mode is None or torch.cuda.is_current_stream_capturing() or ops.KernelTimers.active is not None:
+            return None
+        dev, N = poses.device, int(poses.shape[0])
+        handle = get_mesh_handle(mesh_tensors)
+        parts = tuple(self.sub.parts(N, dev))
+        H, W = int(depth_t.shape[0]), int(depth_t.shape[1])
+        key = (N, H, W, np.asarray(K, dtype=np.float64).tobytes(), id(handle), float(mesh_diameter), parts, bool(self.sub.serial), dev.index)
+
+        def build():
+            oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
+            g = dict(rgb=torch.empty_like(rgb_t), depth=torch.empty_like(depth_t), poses=torch.empty_like(poses), mesh=mesh_tensors,
+                     feats=torch.empty((N, 512), dtype=plan.dtype, device=dev),
+                     ws=[torch.empty(max(16, ops.workspace_bytes(b - a, handle.V, handle.T, oh, ow)), dtype=torch.uint8, device=dev)
+                         for a, b in parts])
+            g["rgb"].copy_(rgb_t); g["depth"].copy_(depth_t); g["poses"].copy_(poses)
+
+            def body(h):
+                a, b = parts[h]
+                AB = torch.empty((2 * (b - a), 6, oh, ow), dtype=plan.dtype, device=dev)
+                batch = make_crop_data_batch(self.cfg["input_resize"], g["poses"][a:b], mesh, g["rgb"], g["depth"], K,
+                                             crop_ratio=self.cfg["crop_ratio"], glctx=glctx, mesh_tensors=mesh_tensors, dataset=self.dataset,
+                                             cfg=self.cfg, mesh_diameter=mesh_diameter, AB=AB, workspace=g["ws"][h])
+                plan.features(batch.AB, slot=h, out=g["feats"][a:b])
+            g["graphs"] = PartGraphs(self.sub, dev, len(parts), body)
+            return g
+        g = self._graphs.get(key, mode, build)
+        if g is None:
+            return None
+        g["rgb"].copy_(rgb_t); g["depth"].copy_(depth_t); g["poses"].copy_(poses)
+        g["graphs"].replay()
+        return g["feats"]
+
+    @torch.inference_mode()
     def predict(self, rgb, depth, K, ob_in_cams, normal_map=None, get_vis=False, mesh=None, mesh_tensors=None,
-                glctx=None, mesh_diameter=None, feature_exchange=None):
+                glctx=None, mesh_diameter=None, feature_exchange=None, graph=None):
         """-> (scores (N,) f32 device tensor = logit + 100, vis).  ``feature_exchange``: optional callable applied to the
-        pooled per-hypothesis features before the cross-hypothesis attention (multi-GPU all-gather hook, dist.py)."""
+        pooled per-hypothesis features before the cross-hypothesis attention (multi-GPU all-gather hook, dist.py).  graph: None =
+        the predictor's setting; True / "auto" / False: hipGraph replay of the per-hypothesis half (_graphed_features)."""
         plan = self.plan()
         dev = self._plan_dev
         if mesh_tensors is None:
@@ -100,20 +143,23 @@ class ScorePredictor:
         oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])
         # the encoder + per-hypothesis attention see one hypothesis at a time: sub-batches on concurrent streams
         # (overlap.py), joined before the cross-hypothesis attention, which needs all N feature rows
-        parts = self.sub.parts(N, dev)
-        feats = torch.empty((N, 512), dtype=plan.dtype, device=dev)
-        streams = self.sub.streams(dev, len(parts))
-        self.sub.fork(streams)
+        feats = None if get_vis else self._graphed_features(rgb_t, depth_t, K, poses, mesh, mesh_tensors, mesh_diameter, glctx,
+                                                            self.graph if graph is None else graph)
         batches = []
-        for h, (a, b) in enumerate(parts):
-            with torch.cuda.stream(streams[h]):
-                AB = torch.empty((2 * (b - a), 6, oh, ow), dtype=plan.dtype, device=dev)
-                batch = make_crop_data_batch(self.cfg["input_resize"], poses[a:b], mesh, rgb_t, depth_t, K,
-                                             crop_ratio=self.cfg["crop_ratio"], glctx=glctx, mesh_tensors=mesh_tensors,
-                                             dataset=self.dataset, cfg=self.cfg, mesh_diameter=mesh_diameter, AB=AB)
-                plan.features(batch.AB, slot=h, out=feats[a:b])
-                batches.append(batch)
-        self.sub.join(streams)
+        if feats is None:
+            parts = self.sub.parts(N, dev)
+            feats = torch.empty((N, 512), dtype=plan.dtype, device=dev)
+            streams = self.sub.streams(dev, len(parts))
+            self.sub.fork(streams)
+            for h, (a, b) in enumerate(parts):
+                with torch.cuda.stream(streams[h]):
+                    AB = torch.empty((2 * (b - a), 6, oh, ow), dtype=plan.dtype, device=dev)
+                    batch = make_crop_data_batch(self.cfg["input_resize"], poses[a:b], mesh, rgb_t, depth_t, K,
+                                                 crop_ratio=self.cfg["crop_ratio"], glctx=glctx, mesh_tensors=mesh_tensors,
+                                                 dataset=self.dataset, cfg=self.cfg, mesh_diameter=mesh_diameter, AB=AB)
+                    plan.features(batch.AB, slot=h, out=feats[a:b])
+                    batches.append(batch)
+            self.sub.join(streams)
         if feature_exchange is not None:
             feats = feature_exchange(feats)
         # bs == N in the reference (predict_score.py:186), so its pairwise tournament always ends after one round

@@ -42,12 +42,33 @@ CONV_BIAS = "separate"
 # other implementation of the policy (cuDNN, MFMA kernels) can be expected to reach (tests/test_gpu_amp.py).
 REVERSED_SUMS = False
 
+# True: the EXACTLY-ROUNDED evaluation of the same policy -- the yardstick the GPU parity gates measure every implementation
+# against (tests/test_gpu_amp.py, tests/golden/make_golden_acc64.py).  Every reduction (convolution, Linear, the two
+# attention products, softmax sums, LayerNorm statistics, token means) is accumulated in float64 from the same fp16-valued
+# operands -- products of fp16 values are exact, so a float64 sum of <= 4608 of them is the exact sum to ~1e-13 relative --
+# and rounded ONCE to the dtype the policy holds it in (the fp32 accumulator / fp32 tensor), then through the policy's own
+# fp16 rounding points.  The fp32-elementwise ops of the policy (BatchNorm affine, exp, LayerNorm affine) are evaluated in
+# float64 and rounded to fp32 as well, so that no implementation's choice of fp32 instruction sequence is baked in.  An
+# implementation that accumulates in fp32 in ANY order (this file with ACC64 = False, cuDNN, the MFMA kernels) differs from
+# it only where its accumulation error moves a value across an fp16 rounding boundary.
+ACC64 = False
+
+
+def _acc(x):
+    """operand of a reduction: float64 under ACC64"""
+    return x.double() if ACC64 else x
+
+
+def _f32(x):
+    """the reduction's result as the policy holds it: fp32"""
+    return x.float()
+
 
 def _conv(x, sd, p, stride):
     w = r16(sd[p + ".weight"].float())
     if REVERSED_SUMS:
         x, w = x.flip(1), w.flip(1)
-    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2)
+    y = _f32(F.conv2d(_acc(x), _acc(w), None, stride=stride, padding=(w.shape[-1] - 1) // 2))
     b = sd.get(p + ".bias")
     if b is None:
         return r16(y)
@@ -57,8 +78,8 @@ def _conv(x, sd, p, stride):
 
 
 def _bn(x, sd, p):
-    return r16(F.batch_norm(x, sd[p + ".running_mean"].float(), sd[p + ".running_var"].float(), sd[p + ".weight"].float(),
-                            sd[p + ".bias"].float(), training=False, eps=1e-5))
+    return r16(_f32(F.batch_norm(_acc(x), _acc(sd[p + ".running_mean"].float()), _acc(sd[p + ".running_var"].float()),
+                                 _acc(sd[p + ".weight"].float()), _acc(sd[p + ".bias"].float()), training=False, eps=1e-5)))
 
 
 def _conv_bn_relu(x, sd, p, stride):
@@ -83,7 +104,7 @@ def _linear(x, w, b):
     x, w = r16(x), r16(w.float())
     if REVERSED_SUMS:
         x, w = x.flip(-1), w.flip(-1)
-    return r16(F.linear(x, w, r16(b.float())))
+    return r16(_f32(F.linear(_acc(x), _acc(w), _acc(r16(b.float())))))
 
 
 def encoder_tokens(A, B, sd, stem, joint, trace=None):
@@ -120,9 +141,9 @@ def attention_flash(qkv, nhead=4):
     D = D3 // 3
     hd = D // nhead
     q, k, v = (_heads(t, Bn, L, nhead, hd) for t in qkv.split(D, dim=-1))
-    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
-    p = torch.exp(s - s.amax(dim=-1, keepdim=True))
-    o = (r16(p) @ v) / p.sum(dim=-1, keepdim=True)
+    s = _f32(_acc(q) @ _acc(k).transpose(-1, -2)) * (1.0 / math.sqrt(hd))
+    p = _f32(torch.exp(_acc(s - s.amax(dim=-1, keepdim=True))))
+    o = _f32((_acc(r16(p)) @ _acc(v)) / _acc(p).sum(dim=-1, keepdim=True))
     return r16(o.permute(0, 2, 1, 3).reshape(Bn, L, D))
 
 
@@ -134,9 +155,9 @@ def attention_explicit(qkv, nhead=4):
     hd = D // nhead
     q, k, v = (_heads(t, Bn, L, nhead, hd) for t in qkv.split(D, dim=-1))
     qs = r16(q * torch.tensor(math.sqrt(1.0 / float(hd)), dtype=torch.float32))
-    s = r16(qs @ k.transpose(-1, -2))
-    p = r16(torch.softmax(s, dim=-1))
-    return r16((p @ v).permute(0, 2, 1, 3).reshape(Bn, L, D))
+    s = r16(_f32(_acc(qs) @ _acc(k).transpose(-1, -2)))
+    p = r16(_f32(torch.softmax(_acc(s), dim=-1)))
+    return r16(_f32(_acc(p) @ _acc(v)).permute(0, 2, 1, 3).reshape(Bn, L, D))
 
 
 def mha(x, sd, p, explicit, nhead=4):
@@ -147,7 +168,7 @@ def mha(x, sd, p, explicit, nhead=4):
 
 
 def _ln(x, sd, p):
-    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"].float(), sd[p + ".bias"].float(), 1e-5)
+    return _f32(F.layer_norm(_acc(x), (x.shape[-1],), _acc(sd[p + ".weight"].float()), _acc(sd[p + ".bias"].float()), 1e-5))
 
 
 def encoder_layer(x, sd, p):
@@ -165,14 +186,14 @@ def refine_forward(A, B, sd, trace=None):
     for name in ("trans", "rot"):
         h = encoder_layer(tok, sd, f"{name}_head.0")
         y = _linear(h, sd[f"{name}_head.1.weight"], sd[f"{name}_head.1.bias"])   # (n, 400, 3|6) fp16 values
-        out[name] = r16(y.mean(dim=1))
+        out[name] = r16(_f32(_acc(y).mean(dim=1)))
     return out
 
 
 @torch.no_grad()
 def score_features(A, B, sd, trace=None):
     tok = encoder_tokens(A, B, sd, "encoderA", "encoderAB", trace)
-    return r16(mha(tok, sd, "att", explicit=True).mean(dim=1))
+    return r16(_f32(_acc(mha(tok, sd, "att", explicit=True)).mean(dim=1)))
 
 
 @torch.no_grad()

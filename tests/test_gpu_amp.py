@@ -3,11 +3,14 @@ the matched-dtype oracle (oracle/nets_amp.py, pinned against the reference's mod
   1. every network kernel against a torch-CPU emulation of the same op with the same rounding points: equal up to
      fp32-summation-order flips (tests/amp_util.py);
   2. encoder / plans against the oracle on the same inputs;
-  3. BASELINE size: 252 hypotheses -- each of 5 refine iterations from bit-identical poses (teacher forced, calibrated
-     stand-in weights) as a THREE-way comparison HIP plan / the nn.Module under torch.autocast on PyTorch-ROCm / oracle,
-     the free-running 5-iteration chain (contraction-scaled heads, weights.CONTRACTION_HEAD_SCALE) and the 252 scores
-     (Kendall tau, top-1), also three ways.  The measured error distributions are written to
-     gpurun_out/parity_amp.json (committed under profiles/)."""
+  3. BASELINE size, against the EXACTLY-ROUNDED evaluation of the policy (oracle/nets_amp.py with ACC64: float64 accumulation
+     at every reduction, the policy's own rounding points; tests/golden/acc64_chain_golden.npz): 252 hypotheses x 5 refine
+     iterations from bit-identical poses with calibrated stand-in weights -- HIP plan, fp32-accumulating oracle and the nn.Module
+     under torch.autocast on PyTorch-ROCm each measured against the yardstick, gate hip_to_exact <= 1.2 x oracle_to_exact;
+     the 5-iteration chain with contraction-scaled heads (weights.CONTRACTION_HEAD_SCALE): 1e-4 rad / 1e-4 m from identical
+     start poses for every hypothesis and iteration, free running with every outlier named; and the 252 scores (logit error,
+     Kendall tau, top-1).  The measured error distributions are written to gpurun_out/parity_amp.json (committed under
+     profiles/)."""
 import json
 import os
 import time
@@ -36,7 +39,7 @@ def _write_report():
     if REPORT:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "parity_amp.json")
+        path = os.path.join(out, os.environ.get("FP_PARITY_REPORT", "parity_amp.json"))
         merged = {}
         if os.path.exists(path):          # several pytest invocations (-k subsets) contribute to one report
             try:
@@ -320,7 +323,7 @@ def test_plans_match_amp_oracle(dev):
     assert np.abs(logits - lref).max() <= 0.05 * max(1.0, lref.std()) + 4 * ulp16(np.abs(lref).max()), (logits, lref)
 
 
-# ------------------------------------------------------------------ 3. BASELINE size
+# ------------------------------------------------------------------ 3. BASELINE size, against the exactly-rounded yardstick
 @pytest.fixture(scope="module")
 def gmesh(scene, dev):
     from foundationpose_amd.Utils import make_mesh_tensors
@@ -336,183 +339,228 @@ def frame(scene, dev):
     return dict(depth_f=d, xyz=xyz, depth_t=torch.as_tensor(d, device=dev), xyz_t=torch.as_tensor(xyz, device=dev))
 
 
+@pytest.fixture(scope="module")
+def acc64():
+    """tests/golden/acc64_chain_golden.npz (make_golden_acc64.py): the reference's autocast policy evaluated with float64
+    accumulation at every reduction and the policy's own rounding points = the EXACTLY-ROUNDED result every implementation of
+    the policy is measured against"""
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "acc64_chain_golden.npz")))
+
+
 def _pct(x):
     x = np.asarray(x, dtype=np.float64)
     return dict(median=float(np.median(x)), p90=float(np.percentile(x, 90)), p99=float(np.percentile(x, 99)), max=float(x.max()))
 
 
-def test_refiner_252_teacher_forced_three_way(scene, dev, gmesh, frame):
-    """252 hypotheses, calibrated stand-in weights (|update| ~ 2 cm / 0.2-0.36 rad), each of the 5 iterations started from
-    the oracle's pose of the previous one (bit-identical inputs), THREE implementations of the reference's autocast policy:
-      hip     the deployed plan: every network op on libfp_amd.so (precision='fp16')
-      lib     the product's nn.Module under torch.autocast('cuda', float16) on PyTorch-ROCm: MIOpen / rocBLAS / ATen
-              kernels (precision='torch_amp') -- nothing of it is ours
-      oracle  oracle/nets_amp.py on the CPU (explicit casts; pinned against the reference under CPU autocast)
-    The refined poses of the three are compared pairwise.  With these weights the policy itself carries ~0.3 % of the update
-    as fp16 rounding noise (each implementation rounds a different fp32 summation order), so 1e-4 rad is not reachable by
-    ANY pair -- the gate is that the HIP plan is as close to the oracle as the library is (x1.5 on median / p90: if all
-    three deviate independently by sigma from the exactly-rounded result, every pair is sqrt(2) sigma apart, but MIOpen's
-    fallback convolution here accumulates in float64, i.e. sigma_lib ~ 0, which makes lib-vs-oracle the smallest pair),
-    or inside the north-star 1e-4.  No slack against a self-made floor; the reversed-summation floor of the oracle against
-    itself is only reported."""
+def _crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def _dist(P, Q):
+    return geodesic(P[:, :3, :3], Q[:, :3, :3]), np.linalg.norm(P[:, :3, 3].astype(np.float64) - Q[:, :3, 3].astype(np.float64), axis=1)
+
+
+# what "as close to the exactly-rounded result as an fp32-accumulating implementation can be" means as a number: the
+# fp32-accumulating oracle (torch CPU kernels: one fp32 summation order) and the HIP plan (MFMA tiles: another) both differ from
+# the yardstick only where their accumulation error moves a value across an fp16 rounding boundary, so their distances to it
+# are two samples of ONE distribution.  1.2 x on median / p90 (252 samples per iteration) and on the pooled p99 / max (1260
+# samples) is the sampling noise of those statistics measured between two fp32 orders of the oracle itself (normal against
+# reversed sums, profiles/r04_gate_noise.json) -- not slack for a different arithmetic.
+EXACT_GATE = 1.2
+
+
+def test_refiner_252_teacher_forced_vs_exact(scene, dev, gmesh, frame, acc64):
+    """252 hypotheses, calibrated stand-in weights (|update| ~ 2 cm / 0.2-0.36 rad), 5 iterations, every implementation started
+    from the SAME pose in every iteration (the exactly-rounded pose of the previous one: bit-identical network inputs), each
+    implementation's refined pose compared with the exactly-rounded one (acc64):
+      hip      the deployed plan: every network op on libfp_amd.so (precision='fp16')
+      oracle   oracle/nets_amp.py with fp32 accumulation on the CPU (pinned against the reference under CPU autocast)
+      lib      the product's nn.Module under torch.autocast('cuda', float16) on PyTorch-ROCm (ATen / rocBLAS kernels) -- reported,
+               not gated: its convolutions start the accumulation from the bias, another rounding sequence than the policy of
+               cuDNN / MIOpen that hip, oracle and the yardstick follow (against the yardstick evaluated with ITS policy in
+               iteration 0: `lib_vs_exact_bias_fused`)
+    Gate (absolute, per implementation): hip_to_exact <= EXACT_GATE x oracle_to_exact on median and p90 of every iteration and
+    on the p99 and maximum pooled over the iterations, for rotation and translation.  With these untrained weights the policy's
+    fp16 roundings alone put ANY fp32-accumulating implementation ~4e-4 rad from the exactly-rounded pose on a 0.2-0.36 rad
+    update (the oracle included), which is why the north-star's 1e-4 rad cannot be asked of this configuration; the 1e-4 gates
+    are test_refiner_contraction_chain_vs_exact (MFMA kernels, same start poses) and test_refiner_fp32_matches_oracle."""
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
     from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
     from oracle import nets_amp, ops as oo
     from oracle import pipeline as op
     cfg = dict(DEFAULT_REFINE_CFG)
     sd = random_state_dict("refine", cfg, seed=0)
-    P0 = scene["poses"]
-    t0 = time.time()
-    trace = []
-    op.refine_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], P0, frame["xyz"], scene["mesh_np"], scene["diameter"],
-                      iteration=5, trace=trace, amp=True)
-    # reported only: same policy, reversed summation order, same inputs
-    nf = 64
-    A, B = torch.from_numpy(trace[0]["A"][:nf]), torch.from_numpy(trace[0]["B"][:nf])
-    nets_amp.REVERSED_SUMS = True
-    try:
-        o_r = nets_amp.refine_forward(A, B, sd)
-    finally:
-        nets_amp.REVERSED_SUMS = False
+    G = acc64
+    assert np.array_equal(G["tf_start"][0], scene["poses"])
     tn = [float(v) for v in cfg["trans_normalizer"]]
-    p_r = oo.pose_update(o_r["trans"].numpy(), o_r["rot"].numpy(), P0[:nf], cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]),
-                         float(scene["diameter"]))
-    floor_R = geodesic(p_r[:, :3, :3], trace[0]["poses"][:nf, :3, :3])
-    floor_t = np.linalg.norm(p_r[:, :3, 3] - trace[0]["poses"][:nf, :3, 3], axis=1)
-    # which conv-bias policy does the library follow?  cuDNN / MIOpen add the bias to the rounded fp16 output ("separate", what
-    # the HIP plan and the oracle's default do); ATen's own convolution (im2col + GEMM, used here because MIOpen has no tuned
-    # gfx950 kernels in this image) starts the fp32 accumulation from the bias ("fused", one rounding, like the CPU backend).
-    # Evaluated on the same 64 hypotheses of iteration 0; the library is compared with BOTH below.
-    nets_amp.CONV_BIAS = "fused"
-    try:
-        o_f = nets_amp.refine_forward(A, B, sd)
-    finally:
-        nets_amp.CONV_BIAS = "separate"
-    p_fused = oo.pose_update(o_f["trans"].numpy(), o_f["rot"].numpy(), P0[:nf], cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]),
-                             float(scene["diameter"]))
-    t_oracle = time.time() - t0
     preds = dict(hip=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16"),
                  lib=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="torch_amp", n_streams=1))
-    rep = dict(oracle_seconds=t_oracle, oracle_reversed_sum_floor_dR=_pct(floor_R), oracle_reversed_sum_floor_dt=_pct(floor_t),
-               iterations=[], seconds=dict(hip=0.0, lib=0.0))
-    start = P0
+    rep = dict(iterations=[], seconds=dict(oracle=0.0, hip=0.0, lib=0.0))
+    pooled = {n: dict(dR=[], dt=[]) for n in ("hip", "oracle", "lib")}
     for it in range(5):
-        tgt = trace[it]["poses"]
-        out = {}
+        start, exact = G["tf_start"][it], G["tf_exact"][it]
+        t0 = time.time()
+        A, B, _, _ = op.refine_inputs(cfg, start, scene["mesh_np"], scene["rgb"], frame["xyz"], scene["K"], scene["diameter"])
+        # the yardstick was minted from exactly these network inputs (bit for bit), or it does not apply
+        assert (_crc(A), _crc(B)) == tuple(int(v) for v in G["tf_crc"][it]), "network inputs differ from the minting run: re-mint"
+        o = nets_amp.refine_forward(torch.from_numpy(A), torch.from_numpy(B), sd)
+        out = dict(oracle=oo.pose_update(o["trans"].numpy(), o["rot"].numpy(), start, cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]),
+                                         float(scene["diameter"])))
+        rep["seconds"]["oracle"] += time.time() - t0
+        if it == 0:
+            # the committed yardstick is what oracle/nets_amp.py with ACC64 computes on THIS machine (first 8 hypotheses)
+            nets_amp.ACC64 = True
+            try:
+                o64 = nets_amp.refine_forward(torch.from_numpy(A[:8]), torch.from_numpy(B[:8]), sd)
+            finally:
+                nets_amp.ACC64 = False
+            for k, g in (("trans", G["tf_trans"][0][:8]), ("rot", G["tf_rot"][0][:8])):
+                d = np.abs(o64[k].numpy() - g)
+                assert (d <= ulp16(g)).all() and np.mean(d == 0) >= 0.9, (k, d.max())
         for name, pred in preds.items():
             t1 = time.time()
-            o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], start, frame["xyz_t"], mesh=scene["mesh"],
+            p, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], start, frame["xyz_t"], mesh=scene["mesh"],
                                 mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=1)
-            out[name] = o.cpu().numpy()
+            out[name] = p.cpu().numpy()
             rep["seconds"][name] += time.time() - t1
             raw = {k: v.cpu().numpy() for k, v in pred.last_raw_output.items()}
             for k in ("trans", "rot"):            # the reference holds the raw outputs in fp16
                 assert np.array_equal(raw[k], raw[k].astype(np.float16).astype(np.float32)), (name, k)
-        out["oracle"] = tgt
-        uR, ut = geodesic(tgt[:, :3, :3], start[:, :3, :3]), np.linalg.norm(tgt[:, :3, 3] - start[:, :3, 3], axis=1)
+        uR, ut = _dist(exact, start)
         row = dict(update_dR=_pct(uR), update_dt=_pct(ut))
-        for a_, b_ in (("hip", "oracle"), ("lib", "oracle"), ("hip", "lib")):
-            dR = geodesic(out[a_][:, :3, :3], out[b_][:, :3, :3])
-            dt = np.linalg.norm(out[a_][:, :3, 3] - out[b_][:, :3, 3], axis=1)
-            row[f"{a_}_vs_{b_}"] = dict(dR=_pct(dR), dt=_pct(dt), rel_dR=_pct(dR / np.maximum(uR, 1e-9)), rel_dt=_pct(dt / np.maximum(ut, 1e-9)))
-        if it == 0:     # the first 64 hypotheses against the oracle evaluated with the other bias policy
-            for name in ("hip", "lib"):
-                dRf = geodesic(out[name][:nf, :3, :3], p_fused[:, :3, :3])
-                dRs = geodesic(out[name][:nf, :3, :3], tgt[:nf, :3, :3])
-                row[f"{name}_first64_vs_oracle_bias_fused_dR"] = _pct(dRf)
-                row[f"{name}_first64_vs_oracle_bias_separate_dR"] = _pct(dRs)
-            rep["library_conv_bias_policy"] = "fused" if row["lib_first64_vs_oracle_bias_fused_dR"]["median"] < \
-                row["lib_first64_vs_oracle_bias_separate_dR"]["median"] else "separate"
+        for name in ("hip", "oracle", "lib"):
+            dR, dt = _dist(out[name], exact)
+            pooled[name]["dR"].append(dR); pooled[name]["dt"].append(dt)
+            row[f"{name}_to_exact"] = dict(dR=_pct(dR), dt=_pct(dt), rel_dR=_pct(dR / np.maximum(uR, 1e-9)))
+        dR, dt = _dist(out["hip"], out["oracle"])
+        row["hip_vs_oracle"] = dict(dR=_pct(dR), dt=_pct(dt))            # the pair previous rounds reported
+        if it == 0:
+            dR, dt = _dist(out["lib"], G["tf_exact_fused_it0"])
+            row["lib_vs_exact_bias_fused"] = dict(dR=_pct(dR), dt=_pct(dt))
         rep["iterations"].append(row)
-        start = tgt
-    REPORT["refiner_252_teacher_forced_three_way"] = rep
+    rep["pooled"] = {n: {q: _pct(np.concatenate(v[q])) for q in ("dR", "dt")} for n, v in pooled.items()}
+    rep["gate"] = f"hip_to_exact <= {EXACT_GATE} x oracle_to_exact: median, p90 per iteration; p99, max pooled over 5 x 252"
+    REPORT["refiner_252_teacher_forced_vs_exact"] = rep
     for it, r in enumerate(rep["iterations"]):
-        h, l = r["hip_vs_oracle"], r["lib_vs_oracle"]
-        for q, tol in (("dR", 1e-4), ("dt", 1e-4)):
-            for stat in ("median", "p90"):
-                assert h[q][stat] <= 1.5 * max(l[q][stat], tol), (it, q, stat, h[q], l[q])
-            assert h[q]["max"] <= 2.0 * max(l[q]["max"], tol), (it, q, h[q], l[q])
-        assert h["rel_dR"]["median"] < 0.01 and h["rel_dt"]["median"] < 0.02, (it, h)
         assert r["update_dR"]["median"] > 0.05                 # full-size updates: nothing is scaled down
+        for q in ("dR", "dt"):
+            for stat in ("median", "p90"):
+                assert r["hip_to_exact"][q][stat] <= EXACT_GATE * r["oracle_to_exact"][q][stat], (it, q, stat, r["hip_to_exact"], r["oracle_to_exact"])
+    for q in ("dR", "dt"):
+        for stat in ("p99", "max"):
+            assert rep["pooled"]["hip"][q][stat] <= EXACT_GATE * rep["pooled"]["oracle"][q][stat], (q, stat, rep["pooled"])
 
 
-@pytest.fixture(scope="module")
-def chain_ref(scene, frame):
-    """the oracle's free-running 5-iteration chain over the 252 hypotheses (autocast policy, contraction-scaled heads)"""
-    from foundationpose_amd.weights import CONTRACTION_HEAD_SCALE, DEFAULT_REFINE_CFG, random_state_dict
+def _input_flips(cfg, scene, frame, pa, pb):
+    """discrete differences between the network inputs of ONE hypothesis rendered at two (nearly equal) poses: pixels whose
+    coverage differs (rendered xyz present / absent), rendered pixels whose colour jumps (another texel / triangle), observed
+    pixels whose nearest-neighbour xyz source differs"""
     from oracle import pipeline as op
-    cfg = dict(DEFAULT_REFINE_CFG)
-    sd = random_state_dict("refine", cfg, seed=0, head_scale=CONTRACTION_HEAD_SCALE)
-    ref = op.refine_predict(cfg, sd, scene["rgb"], frame["depth_f"], scene["K"], scene["poses"], frame["xyz"], scene["mesh_np"],
-                            scene["diameter"], iteration=5, amp=True)
-    return dict(cfg=cfg, sd=sd, ref=ref)
+    r = []
+    for p in (pa, pb):
+        A, B, _, _ = op.refine_inputs(cfg, p[None], scene["mesh_np"], scene["rgb"], frame["xyz"], scene["K"], scene["diameter"])
+        r.append((A[0], B[0]))
+    (A0, B0), (A1, B1) = r
+    cov0, cov1 = np.abs(A0[3:]).sum(0) > 0, np.abs(A1[3:]).sum(0) > 0
+    both = cov0 & cov1
+    return dict(coverage=int((cov0 != cov1).sum()), colour=int(((np.abs(A0[:3] - A1[:3]).max(0) > 0.05) & both).sum()),
+                observed_nn=int((np.abs(B0[3:] - B1[3:]).max(0) > 2e-3).sum()))
 
 
-def test_refiner_252_free_running_chain(scene, dev, gmesh, frame, chain_ref):
-    """The chain the metric times (estimater.py:215: 252 hypotheses, iteration=5, free running) in the deployed dtype, with
-    contraction-scaled stand-in heads (weights.CONTRACTION_HEAD_SCALE: a trained refiner is a contraction, the unscaled
-    stand-in expands a last-bit difference 40-120x per iteration, so an unscaled free-running chain compares chaotic
-    trajectories).  Reported next to the same chain on PyTorch-ROCm under autocast.  This is NOT the parity gate of the
-    deployed dtype (that is the full-size three-way test above); it checks that five iterations chained on the device -- no
-    host round trip, sub-batches on two streams -- end where the oracle's chain ends: the bulk inside the north-star
-    1e-4 rad / 1e-4 m, the tail (hypotheses where a crop pixel flips coverage or its nearest-neighbour source between the two
-    runs) bounded, and no worse than the library's."""
+def test_refiner_contraction_chain_vs_exact(scene, dev, gmesh, frame, acc64):
+    """The chain the metric times (estimater.py:215: 252 hypotheses, iteration=5) on the MFMA kernels against the exactly-rounded
+    chain (acc64 fr_chain), with contraction-scaled stand-in heads (weights.CONTRACTION_HEAD_SCALE: a trained refiner is a
+    contraction; the unscaled stand-in expands a last-bit difference 40-120 x per iteration).
+      (a) THE pose-level north-star gate on the MFMA kernels: from the exact chain's pose of every iteration (bit-identical
+          network inputs), one iteration of the HIP plan ends within 1e-4 rad / 1e-4 m of the exactly-rounded pose for ALL 252
+          hypotheses x 5 iterations -- asserted at 2e-5 rad / 2e-6 m, the measured level leaves a decade of margin;
+      (b) free running (predict(iteration=5): device-resident loop, sub-batches on two streams, hipGraph replay): the bulk inside
+          1e-4 rad, every hypothesis inside 3e-4 rad / 1e-4 m, and every hypothesis outside 1e-4 rad NAMED: the iteration at
+          which it leaves the exact chain and the discrete input events between the two runs at that iteration (a crop pixel
+          changing coverage, a rendered pixel jumping to another texel, an observed pixel taking another nearest-neighbour
+          source) -- with (a) holding at that very iteration, the arithmetic is not the cause;
+      (c) the 5-iteration call returns the bits of five 1-iteration calls chained through the host."""
     from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
-    from foundationpose_amd.weights import CONTRACTION_HEAD_SCALE
-    cfg, sd, ref = chain_ref["cfg"], chain_ref["sd"], chain_ref["ref"]
+    from foundationpose_amd.weights import CONTRACTION_HEAD_SCALE, DEFAULT_REFINE_CFG, random_state_dict
+    cfg = dict(DEFAULT_REFINE_CFG)
+    assert float(acc64["head_scale"]) == CONTRACTION_HEAD_SCALE
+    sd = random_state_dict("refine", cfg, seed=0, head_scale=CONTRACTION_HEAD_SCALE)
+    chain = acc64["fr_chain"]
     P0 = scene["poses"]
-    mR, mt = geodesic(ref[:, :3, :3], P0[:, :3, :3]), np.linalg.norm(ref[:, :3, 3] - P0[:, :3, 3], axis=1)
-    rep = dict(head_scale=CONTRACTION_HEAD_SCALE, total_motion_dR=_pct(mR), total_motion_dt=_pct(mt))
-    preds = {}
-    for name, kw in (("hip", dict(precision="fp16")), ("lib", dict(precision="torch_amp", n_streams=1))):
-        pred = preds[name] = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, **kw)
-        out, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], mesh=scene["mesh"], mesh_tensors=gmesh,
-                              mesh_diameter=scene["diameter"], iteration=5)
-        out = out.cpu().numpy()
-        dR, dt = geodesic(out[:, :3, :3], ref[:, :3, :3]), np.linalg.norm(out[:, :3, 3] - ref[:, :3, 3], axis=1)
-        rep[name] = dict(dR=_pct(dR), dt=_pct(dt), rel_dR=_pct(dR / np.maximum(mR, 1e-9)), frac_within_1e4_rad=float(np.mean(dR <= 1e-4)),
-                         frac_within_1e4_m=float(np.mean(dt <= 1e-4)))
-    REPORT["refiner_252_free_running_5_iterations"] = rep
-    h, l = rep["hip"], rep["lib"]
-    assert mR.mean() > 1e-3                                   # the chain moves the poses by >> the tolerance
-    assert h["frac_within_1e4_rad"] >= min(0.97, l["frac_within_1e4_rad"] - 0.01) and h["frac_within_1e4_m"] >= 0.99, rep
-    assert h["dR"]["median"] <= 1.5 * max(l["dR"]["median"], 1e-5) and h["dR"]["max"] <= 1e-3 and h["dt"]["max"] <= 1e-4, rep
-    assert h["rel_dR"]["median"] < 0.05, rep
+    assert np.array_equal(chain[0], P0)
+    pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16")
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+
+    def run(P, it):
+        o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P, frame["xyz_t"], iteration=it, **kw)
+        return o.cpu().numpy()
+    # (a) teacher forced along the exact chain
+    tf = [run(chain[k], 1) for k in range(5)]
+    tfR = np.stack([_dist(tf[k], chain[k + 1])[0] for k in range(5)])
+    tft = np.stack([_dist(tf[k], chain[k + 1])[1] for k in range(5)])
+    upd = np.stack([_dist(chain[k + 1], chain[k])[0] for k in range(5)])
+    rep = dict(head_scale=CONTRACTION_HEAD_SCALE, update_dR_per_iteration=_pct(upd), teacher_forced_dR=_pct(tfR), teacher_forced_dt=_pct(tft),
+               total_motion_dR=_pct(_dist(chain[5], P0)[0]), total_motion_dt=_pct(_dist(chain[5], P0)[1]))
+    # (b), (c) free running
+    out5 = run(P0, 5)
+    per, cur = [], P0
+    for k in range(5):
+        cur = run(cur, 1)
+        per.append(cur)
+    rep["five_calls_equal_one_call"] = bool(np.array_equal(per[-1], out5))
+    dR = np.stack([_dist(per[k], chain[k + 1])[0] for k in range(5)])          # (5, 252)
+    dt = np.stack([_dist(per[k], chain[k + 1])[1] for k in range(5)])
+    rep.update(free_running_dR=_pct(dR[-1]), free_running_dt=_pct(dt[-1]), frac_within_1e4_rad=float(np.mean(dR[-1] <= 1e-4)),
+               frac_within_1e4_m=float(np.mean(dt[-1] <= 1e-4)), outliers=[])
+    for h in np.nonzero((dR[-1] > 1e-4) | (dt[-1] > 1e-4))[0]:
+        # the iteration at which hypothesis h leaves the exact chain: the largest single-iteration growth of its deviation
+        grow = np.diff(np.concatenate([[0.0], dR[:, h]]))
+        k = int(np.argmax(grow))
+        pa, pb = (P0[h], P0[h]) if k == 0 else (per[k - 1][h], chain[k][h])
+        flips = _input_flips(cfg, scene, frame, pa, pb) if k > 0 else dict(coverage=0, colour=0, observed_nn=0)
+        rep["outliers"].append(dict(hypothesis=int(h), final_dR=float(dR[-1, h]), final_dt=float(dt[-1, h]), dR_by_iteration=[float(v) for v in dR[:, h]],
+                                    leaves_chain_at_iteration=k, start_pose_dR_there=float(0.0 if k == 0 else _dist(pa[None], pb[None])[0][0]),
+                                    input_events_there=flips, teacher_forced_dR_there=float(tfR[k, h])))
+    REPORT["refiner_252_contraction_chain_vs_exact"] = rep
+    assert upd.mean() > 1e-4 and rep["total_motion_dR"]["median"] > 1e-3      # the chain moves the poses by >> the tolerance
+    assert tfR.max() <= 2e-5 and tft.max() <= 2e-6, rep                            # (a)
+    assert rep["five_calls_equal_one_call"], rep                                   # (c)
+    assert rep["frac_within_1e4_rad"] >= 0.97 and dR[-1].max() <= 3e-4 and dt[-1].max() <= 1e-4, rep      # (b)
+    for o in rep["outliers"]:
+        assert o["leaves_chain_at_iteration"] > 0 and sum(o["input_events_there"].values()) > 0, o
     # last_trans_update / last_rot_update: the reference's semantics (metric delta, applied 3x3 rotation)
-    pred = preds["hip"]
     assert pred.last_trans_update.shape == (252, 3) and pred.last_rot_update.shape == (252, 3, 3)
     Rd = pred.last_rot_update.cpu().numpy()
     assert np.abs(Rd @ Rd.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
 
 
-def test_scorer_252_three_way(scene, dev, gmesh, frame, chain_ref):
-    """the 252 scores of the oracle's refined poses: HIP plan / PyTorch-ROCm under autocast / autocast oracle (and the fp32
-    oracle as a yardstick): Kendall tau, top-1, logit errors"""
+def test_scorer_252_vs_exact(scene, dev, gmesh, frame, acc64):
+    """the 252 scores of the exact chain's refined poses: HIP plan, fp32-accumulating oracle and PyTorch-ROCm under autocast,
+    each against the exactly-rounded scores (acc64 score_exact): logit errors, Kendall tau, top-1.  Gate: hip as close to the
+    exact scores as the oracle is (EXACT_GATE on median / p90 / max of the logit error, tau within 0.003, same best hypothesis)."""
     from foundationpose_amd.predict_score import ScorePredictor
     from foundationpose_amd.weights import DEFAULT_SCORE_CFG, random_state_dict
     from oracle import pipeline as op
-    ref = chain_ref["ref"]
+    ref = acc64["fr_chain"][5]
+    sx = acc64["score_exact"].astype(np.float64)
     scfg = dict(DEFAULT_SCORE_CFG)
     ssd = random_state_dict("score", scfg, seed=0)
-    sref = op.score_predict(scfg, ssd, scene["rgb"], frame["depth_f"], scene["K"], ref, scene["mesh_np"], scene["diameter"], amp=True)
-    s32 = op.score_predict(scfg, ssd, scene["rgb"], frame["depth_f"], scene["K"], ref, scene["mesh_np"], scene["diameter"], amp=False)
-    scorer = ScorePredictor(cfg=scfg, state_dict=ssd, device=dev, precision="fp16")
-    s, _ = scorer.predict(scene["rgb"], frame["depth_t"], scene["K"], ref, mesh=scene["mesh"], mesh_tensors=gmesh,
-                          mesh_diameter=scene["diameter"])
-    s = s.cpu().numpy()
-    tau, tau_floor = kendall_tau(s, sref), kendall_tau(s32, sref)
-    srep = dict(kendall_tau_vs_amp_oracle=tau, kendall_tau_fp32_oracle_vs_amp_oracle=tau_floor, top1_equal=bool(np.argmax(s) == np.argmax(sref)),
-                hip_top1_rank_in_oracle=int(np.argsort(-sref).tolist().index(int(np.argmax(s)))), abs_err=_pct(np.abs(s - sref)),
-                fp32_vs_amp_abs_err=_pct(np.abs(s32 - sref)), logit_std=float(sref.std()))
-    # third implementation: the nn.Module under torch.autocast on PyTorch-ROCm (MIOpen / rocBLAS / ATen)
-    lib = ScorePredictor(cfg=scfg, state_dict=ssd, device=dev, precision="torch_amp", n_streams=1)
-    sl, _ = lib.predict(scene["rgb"], frame["depth_t"], scene["K"], ref, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
-    sl = sl.cpu().numpy()
-    srep.update(kendall_tau_lib_vs_amp_oracle=kendall_tau(sl, sref), kendall_tau_hip_vs_lib=kendall_tau(s, sl),
-                lib_abs_err=_pct(np.abs(sl - sref)), hip_vs_lib_abs_err=_pct(np.abs(s - sl)), lib_top1_equal=bool(np.argmax(sl) == np.argmax(sref)))
-    REPORT["scorer_252"] = srep
-    assert tau >= srep["kendall_tau_lib_vs_amp_oracle"] - 0.01, srep          # as close to the oracle as the library is
-    assert np.abs(s - sref).max() <= 1.5 * max(np.abs(sl - sref).max(), 0.02 * sref.std()), srep
-    assert tau >= min(0.98, tau_floor - 0.01), srep
-    assert srep["hip_top1_rank_in_oracle"] <= 2, srep
-    assert np.abs(s - sref).max() <= max(4 * np.abs(s32 - sref).max(), 0.02 * sref.std()), srep
+    tr = []
+    s32 = op.score_predict(scfg, ssd, scene["rgb"], frame["depth_f"], scene["K"], ref, scene["mesh_np"], scene["diameter"], amp=True, trace=tr)
+    assert (_crc(tr[0]["A"]), _crc(tr[0]["B"])) == tuple(int(v) for v in acc64["score_crc"]), "network inputs differ from the minting run"
+    res = dict(oracle=s32)
+    for name, kw in (("hip", dict(precision="fp16")), ("lib", dict(precision="torch_amp", n_streams=1))):
+        sp = ScorePredictor(cfg=scfg, state_dict=ssd, device=dev, **kw)
+        s, _ = sp.predict(scene["rgb"], frame["depth_t"], scene["K"], ref, mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+        res[name] = s.cpu().numpy()
+    srep = dict(logit_std=float(sx.std()))
+    for name, s in res.items():
+        srep[name] = dict(abs_err=_pct(np.abs(s - sx)), kendall_tau=kendall_tau(s, sx), top1_equal=bool(np.argmax(s) == np.argmax(sx)),
+                          top1_rank_in_exact=int(np.argsort(-sx).tolist().index(int(np.argmax(s)))))
+    REPORT["scorer_252_vs_exact"] = srep
+    h, o = srep["hip"], srep["oracle"]
+    for stat in ("median", "p90", "max"):
+        assert h["abs_err"][stat] <= EXACT_GATE * max(o["abs_err"][stat], float(ulp16(np.abs(sx - 100.0).max()))), srep
+    assert h["kendall_tau"] >= o["kendall_tau"] - 0.003 and h["kendall_tau"] >= 0.98, srep
+    assert h["top1_rank_in_exact"] <= 1, srep

@@ -555,6 +555,59 @@ def test_sub_batches_on_concurrent_streams_change_nothing(scene, dev, gmesh, fra
             assert torch.equal(res[1][4][k], res[ns][4][k])
 
 
+def test_graphed_predict_is_the_eager_predict(scene, dev, gmesh, frame):
+    """PoseRefinePredictor.predict / ScorePredictor.predict with graph=True (one linear hipGraph per sub-batch, replayed on the
+    sub-batch streams; predict_pose_refine.refine_graphed, predict_score._graphed_features) return the bits of the eager
+    launches: first call (capture + replay), replay with new inputs, a second key, the shared-translation form of register(),
+    and "auto" (eager at the first sighting of a key, captured at the second)"""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    rgb, depth, xyz = frame["rgb_t"], frame["depth_t"], frame["xyz_t"]
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev, graph=False)
+    scorer = ScorePredictor(cfg=dict(DEFAULT_SCORE_CFG), state_dict=random_state_dict("score", seed=0), device=dev, graph=False)
+
+    def both(P, it, graph, shared=None):
+        p, _ = refiner.predict(rgb, depth, scene["K"], P, xyz, iteration=it, graph=graph, shared_translation=shared, **kw)
+        out = [p.clone(), refiner.last_trans_update.clone(), refiner.last_rot_update.clone()] + \
+              [v.clone() for _, v in sorted(refiner.last_raw_output.items())]
+        s, _ = scorer.predict(rgb, depth, scene["K"], p, graph=graph, **kw)
+        return out + [s.clone()]
+
+    def same(a, b, what):
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (what, i)
+    P = scene["poses"][:75]
+    Q = np.ascontiguousarray(scene["poses"][75:150])
+    eager = both(P, 3, False)
+    same(both(P, 3, True), eager, "capture + first replay")
+    assert len(refiner._graphs.items) == 1 and len(scorer._graphs.items) == 1
+    eq = both(Q, 3, False)
+    same(both(Q, 3, True), eq, "replay with other poses")
+    same(both(P, 3, True), eager, "replay with the first poses again")
+    assert len(refiner._graphs.items) == 1
+    rgb2 = (rgb * 0.9).contiguous()                       # another frame through the same graphs
+    rgb, keep = rgb2, rgb
+    e2 = both(P, 3, False)
+    same(both(P, 3, True), e2, "replay with another frame")
+    rgb = keep
+    same(both(P[:40], 2, True), both(P[:40], 2, False), "a second key (one part, two iterations)")
+    assert len(refiner._graphs.items) == 2
+    # register(): every hypothesis at one translation, the first iteration shares the observed crop
+    S = P.copy()
+    S[:, :3, 3] = S[0, :3, 3]
+    same(both(S, 2, True, shared=True), both(S, 2, False, shared=True), "shared translation")
+    # "auto": the first sighting of a key runs eagerly, the second captures
+    n0 = len(refiner._graphs.items)
+    a1 = both(P[:50], 2, "auto")
+    assert len(refiner._graphs.items) == n0
+    a2 = both(P[:50], 2, "auto")
+    assert len(refiner._graphs.items) == n0 + 1
+    same(a1, a2, "auto: eager then graph")
+    same(a1, both(P[:50], 2, False), "auto vs eager")
+
+
 def test_linear_layernorm_is_the_two_kernel_path(dev):
     """fp_linear_layernorm_fwd (out_proj / linear2 + residual + LayerNorm in one launch) returns the bits of
     fp_igemm_f16_fwd followed by fp_layernorm_res_fwd: both residual forms, full and ragged row counts, one or both outputs"""
