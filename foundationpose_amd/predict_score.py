@@ -110,13 +110,21 @@ class ScorePredictor:
                          for a, b in parts])
             g["rgb"].copy_(rgb_t); g["depth"].copy_(depth_t); g["poses"].copy_(poses)
 
+            normalize = bool(self.cfg["normalize_xyz"])
+
             def body(h):
+                # the launches of make_crop_data_batch without its BatchPoseData bookkeeping (whose intrinsics / diameter tensors
+                # are host -> device copies, which a stream capture does not allow): crop windows, rendered crop, observed crop
                 a, b = parts[h]
-                AB = torch.empty((2 * (b - a), 6, oh, ow), dtype=plan.dtype, device=dev)
-                batch = make_crop_data_batch(self.cfg["input_resize"], g["poses"][a:b], mesh, g["rgb"], g["depth"], K,
-                                             crop_ratio=self.cfg["crop_ratio"], glctx=glctx, mesh_tensors=mesh_tensors, dataset=self.dataset,
-                                             cfg=self.cfg, mesh_diameter=mesh_diameter, AB=AB, workspace=g["ws"][h])
-                plan.features(batch.AB, slot=h, out=g["feats"][a:b])
+                n = b - a
+                P = g["poses"][a:b]
+                AB = torch.empty((2 * n, 6, oh, ow), dtype=plan.dtype, device=dev)
+                tf_to_crops, bbox2d = ops.crop_windows(P, K, mesh_diameter, self.cfg["crop_ratio"], (ow, oh))
+                ops.render_crops(handle, P, bbox2d, K, H, W, out_hw=(oh, ow), mesh_diameter=mesh_diameter, xyz_thr=0.1,
+                                 normalize_xyz=normalize, A_out=AB[:n], workspace=g["ws"][h])
+                ops.warp_crops(g["rgb"], None, g["depth"], tf_to_crops, K, P, mesh_diameter, ops.MODE_SCORE, normalize_xyz=normalize,
+                               out_hw=(oh, ow), B_out=AB[n:])
+                plan.features(AB, slot=h, out=g["feats"][a:b])
             g["graphs"] = PartGraphs(self.sub, dev, len(parts), body)
             return g
         g = self._graphs.get(key, mode, build)

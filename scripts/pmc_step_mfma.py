@@ -26,7 +26,7 @@ if len(marks) >= 2:
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for i in ids:
     d = by_disp[i]
-    name = d["name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-48:]
+    name = d["name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-48:]
     a = agg[name]
     a["launches"] += 1
     for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "ns"):

@@ -38,7 +38,7 @@ def load(path, counter):
                 v = float(r["Counter_Value"])
                 tot[entry] += v
                 n[entry] += 1
-                k = kern[(entry, r["Kernel_Name"].split("(")[0][-60:])]
+                k = kern[(entry, r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:])]
                 k[0] += 1
                 k[1] += v
                 break
