@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import bench
 from foundationpose_amd import ops, _lib
-dev = torch.device("cuda:0"); N = 252
+dev = torch.device("cuda:0"); N = int(os.environ.get("FP_N", "252"))
 sc = bench.build_scene(dev, 0, N); h = sc["gm"]["_handle"]
 poses = torch.as_tensor(sc["poses"], device=dev)
 tf, bb = ops.crop_windows(poses, sc["K"], sc["diameter"], 1.2, (160, 160))
