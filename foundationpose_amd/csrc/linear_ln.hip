@@ -60,7 +60,7 @@ struct LinearLnParams {
   float* y32;             // either may be null
   _Float16* y16;
   int M, K;
-  float* part;            // MEAN variant (profiling build): per-tile partial column sums [tiles][2][512]; S = rows per group
+  float* part;            // MEAN forms: chunk sums [M / 16][512] (16 consecutive rows each); S = rows per group
   const _Float16* W2;     // FFN variant (profiling build): second Linear (512, 512) and its bias; Wt / bias are the first (+ ReLU)
   const float* bias2;
 };
@@ -73,9 +73,12 @@ __device__ __forceinline__ void ll_dma16(const __amdgpu_buffer_rsrc_t& rs, void*
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-// MEAN (profiling build only, fp_linear_layernorm_mean_fwd): instead of writing the normalised rows, add them up per group of
-// p.S rows (the token mean of refine_network.py:90-91 fused with norm2): per-tile partial column sums, finished by
-// k_ln_mean_finish in a fixed order.
+// MEAN (fp_ffn_layernorm_mean_fwd; profiling build: fp_linear_layernorm_mean_fwd): instead of writing the normalised rows, add them up
+// per group of p.S rows (the token mean of refine_network.py:90-91 fused with norm2).  The order of that sum must not depend on WHERE
+// in the batch a hypothesis sits (sub-batches, shards and single batches have to agree bit for bit): a wave
+// therefore owns 16 CONSECUTIVE rows of the tile -- a chunk that lies inside one hypothesis because p.S and the tile height are
+// multiples of 16 -- adds them in row order and writes the chunk sum; k_ln_mean_finish adds a hypothesis's S / 16 chunk sums in
+// chunk order.
 // FFN (profiling build only, fp_ffn_layernorm_mean_fwd): TWO Linears back to back on the tile, linear1 + ReLU -> the 128 x 512
 // intermediate parked in the epilogue tile -> linear2 reading its A fragments from that tile and its weights straight from L2 into
 // registers (a wave owns 64 output channels, so nobody shares its weight rows: no staging, no barrier in the second loop).
@@ -198,10 +201,12 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 
   // past the end of the matrix reads the last row instead: normalised, never stored
   half8 tk[LL_R];
   float rs[LL_R][8];
+  // tile row of the wave's (t0 + u)-th row: interleaved (wave w: rows w, w + 8, ...) or, for the MEAN forms, one contiguous chunk
+  auto tile_row = [&](int k) { return MEAN ? wid * LL_ROWS_PER_WAVE + k : wid + LL_NW * k; };
   auto request_resid = [&](int t0) {
 #pragma unroll
     for (int u = 0; u < LL_R; ++u) {
-      const int m = m0 + wid + LL_NW * (t0 + u);
+      const int m = m0 + tile_row(t0 + u);
       const int mc = m < p.M ? m : p.M - 1;
       if (p.x32) {
         load8f(p.x32 + (size_t)mc * 512 + lane * 8, rs[u]);
@@ -318,20 +323,15 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 
     load8f(p.gamma + lane * 8, gm);
     load8f(p.beta + lane * 8, bt);
   }
-  // MEAN: a tile of BM <= p.S rows touches at most two groups; rows below `second_group_row` belong to the first
-  float csum[2][8];
-  int second_group_row = 0;
-  if constexpr (MEAN) {
+  float csum[8];           // MEAN: the sum of this wave's chunk of LL_ROWS_PER_WAVE consecutive rows, in row order
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { csum[0][e] = 0.f; csum[1][e] = 0.f; }
-    second_group_row = (m0 / p.S + 1) * p.S;
-  }
+  for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll 1
   for (int t0 = 0; t0 < LL_ROWS_PER_WAVE; t0 += LL_R) {
     float f[LL_R][8];
 #pragma unroll
     for (int u = 0; u < LL_R; ++u) {
-      const int r = wid + LL_NW * (t0 + u);
+      const int r = tile_row(t0 + u);
       const half8 b = *reinterpret_cast<const half8*>(E + r * (2 * LL_BN) + ((lane ^ (r & 15)) << 4));
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -344,21 +344,16 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 
     if constexpr (MEAN) {
 #pragma unroll
       for (int u = 0; u < LL_R; ++u) {
-        const int m = m0 + wid + LL_NW * (t0 + u);
+        const int m = m0 + tile_row(t0 + u);
         if (m >= p.M) continue;                            // wave-uniform
-        if (m < second_group_row) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) csum[0][e] += f[u][e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) csum[1][e] += f[u][e];
-        }
+        for (int e = 0; e < 8; ++e) csum[e] += f[u][e];
       }
       continue;
     }
 #pragma unroll
     for (int u = 0; u < LL_R; ++u) {
-      const int m = m0 + wid + LL_NW * (t0 + u);
+      const int m = m0 + tile_row(t0 + u);
       if (m >= p.M) continue;                              // wave-uniform
       half8 h;
 #pragma unroll
@@ -368,33 +363,21 @@ __global__ __launch_bounds__(LL_THREADS, (LlTile<BM, NST>::WG_PER_CU == 2 ? 4 : 
     }
   }
   if constexpr (MEAN) {
-    // wave partials -> LDS (the E tile is free once every wave has read its rows) -> one thread per channel adds the eight
-    // waves in order -> this tile's two partial sums
-    __syncthreads();
-    float* P = reinterpret_cast<float*>(smem);   // [wave][slot][512]
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) store8f(P + (wid * 2 + sl) * 512 + lane * 8, csum[sl]);
-    __syncthreads();
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      float a = 0.f;
-#pragma unroll
-      for (int w = 0; w < LL_NW; ++w) a += P[(w * 2 + sl) * 512 + tid];
-      p.part[((size_t)blockIdx.x * 2 + sl) * 512 + tid] = a;
-    }
+    static_assert(!MEAN || LL_ROWS_PER_WAVE == 16, "a wave's chunk is 16 rows: groups are multiples of 16 rows");
+    // chunk q = (m0 + 16 wid) / 16 of the whole matrix: its sum goes to part[q][512]; chunks past the end do not exist
+    const int mrow = m0 + wid * LL_ROWS_PER_WAVE;
+    if (mrow < p.M) store8f(p.part + (size_t)(mrow / LL_ROWS_PER_WAVE) * 512 + lane * 8, csum);
   }
 }
 
-// out[g][c] = mean over the rows of group g of LN(...) * gamma + beta from the tiles' partial sums, tiles in increasing order
+// out[g][c] = mean over the rows of group g of LN(...) * gamma + beta from the chunk sums (16 rows each), chunks in increasing order
 __global__ __launch_bounds__(512) void k_ln_mean_finish(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ out, int S, int BM) {
+                                                       const float* __restrict__ beta, float* __restrict__ out, int S) {
   const int g = blockIdx.x, c = threadIdx.x;
-  const int t_first = (g * S) / BM, t_last = ((g + 1) * S - 1) / BM;
+  const int nch = S / 16;
+  const float* src = part + (size_t)g * nch * 512 + c;
   float a = 0.f;
-  for (int t = t_first; t <= t_last; ++t) {
-    const int sl = g - (t * BM) / S;            // 0: the group the tile starts in, 1: the next one
-    a += part[((size_t)t * 2 + sl) * 512 + c];
-  }
+  for (int k = 0; k < nch; ++k) a += src[(size_t)k * 512];
   a *= 1.0f / (float)S;
   out[(size_t)g * 512 + c] = fmaf(a, gamma[c], beta[c]);   // mean(LN(x) * gamma + beta) = mean(LN(x)) * gamma + beta
 }
@@ -414,7 +397,7 @@ int ll_launch(const LinearLnParams& p, hipStream_t stream) {
 // Profiling build only (not in include/fp_amd.h, bound ad hoc by scripts/bench_linear_ln_mean.py): linear2 + residual + norm2 +
 // token mean of the refiner's encoder layer in one launch + a finish kernel; = fp_igemm_f16_fwd + fp_colmean_f16_fwd with another
 // (fixed) summation order of the token mean, so it has to pass the parity gates before it can replace them.
-// out (groups, 512) f32; workspace: ceil(groups * rows_per_group / 128) * 2 * 512 floats.
+// out (groups, 512) f32; workspace: groups * rows_per_group / 16 * 512 floats.
 extern "C" int fp_linear_layernorm_mean_fwd(const void* x16, const void* w16, const float* bias, const float* x32, const float* gamma,
                                             const float* beta, float eps, float* out, float* workspace, size_t workspace_bytes,
                                             int groups, int rows_per_group, int K, int D, void* stream) {
@@ -422,11 +405,11 @@ extern "C" int fp_linear_layernorm_mean_fwd(const void* x16, const void* w16, co
   if (groups == 0) return FP_OK;
   FP_REQUIRE(x16 && w16 && x32 && gamma && beta && out && workspace, "fp_linear_layernorm_mean_fwd: NULL tensor");
   FP_REQUIRE(D == 512 && K > 0 && K % LL_BK == 0, "fp_linear_layernorm_mean_fwd: D must be 512, K a multiple of %d", LL_BK);
-  FP_REQUIRE(rows_per_group >= 128, "fp_linear_layernorm_mean_fwd: a tile of 128 rows may touch two groups at most");
+  FP_REQUIRE(rows_per_group >= 16 && rows_per_group % 16 == 0, "fp_linear_layernorm_mean_fwd: rows_per_group must be a multiple of 16");
   const long long M = (long long)groups * rows_per_group;
   FP_REQUIRE(M * K < (1ll << 30), "fp_linear_layernorm_mean_fwd: operands exceed 2 GiB");
   const int tiles = fp_cdiv((int)M, 128);
-  FP_REQUIRE(workspace_bytes >= (size_t)tiles * 2 * 512 * sizeof(float), "fp_linear_layernorm_mean_fwd: workspace too small");
+  FP_REQUIRE(workspace_bytes >= (size_t)(M / 16) * 512 * sizeof(float), "fp_linear_layernorm_mean_fwd: workspace too small");
   LinearLnParams p;
   p.X = (const _Float16*)x16; p.Wt = (const _Float16*)w16; p.bias = bias; p.x32 = x32; p.tok16 = nullptr; p.pe = nullptr;
   p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M; p.K = K;
@@ -435,7 +418,7 @@ extern "C" int fp_linear_layernorm_mean_fwd(const void* x16, const void* w16, co
   FP_SET_MAX_LDS((k_linear_ln512<128, 3, true>), LDS);
   hipLaunchKernelGGL((k_linear_ln512<128, 3, true>), dim3(tiles), dim3(LL_THREADS), LDS, (hipStream_t)stream, p);
   hipLaunchKernelGGL(k_ln_mean_finish, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, gamma, beta, out,
-                     rows_per_group, 128);
+                     rows_per_group);
   FP_CHECK_LAUNCH("fp_linear_layernorm_mean_fwd");
   return FP_OK;
 }
@@ -450,13 +433,14 @@ extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1, const 
   FP_REQUIRE(groups >= 0, "fp_ffn_layernorm_mean_fwd: groups < 0");
   if (groups == 0) return FP_OK;
   FP_REQUIRE(y16 && w1 && w2 && x32 && gamma && beta && out && workspace, "fp_ffn_layernorm_mean_fwd: NULL tensor");
-  FP_REQUIRE(rows_per_group >= 128, "fp_ffn_layernorm_mean_fwd: a tile of 128 rows may touch two groups at most");
+  FP_REQUIRE(rows_per_group >= 16 && rows_per_group % 16 == 0,
+             "fp_ffn_layernorm_mean_fwd: rows_per_group=%d must be a multiple of 16 (a wave sums 16 consecutive rows, which have to belong to one group)", rows_per_group);
   const long long M = (long long)groups * rows_per_group;
   FP_REQUIRE(M * 512 < (1ll << 30), "fp_ffn_layernorm_mean_fwd: operands exceed 2 GiB");
   FP_REQUIRE((((size_t)y16 | (size_t)w1 | (size_t)w2 | (size_t)b1 | (size_t)b2 | (size_t)x32 | (size_t)gamma | (size_t)beta) & 15) == 0,
              "fp_ffn_layernorm_mean_fwd: tensors must be 16-byte aligned");
   const int tiles = fp_cdiv((int)M, 128);
-  FP_REQUIRE(workspace_bytes >= (size_t)tiles * 2 * 512 * sizeof(float), "fp_ffn_layernorm_mean_fwd: workspace too small");
+  FP_REQUIRE(workspace_bytes >= (size_t)(M / 16) * 512 * sizeof(float), "fp_ffn_layernorm_mean_fwd: workspace too small");
   LinearLnParams p;
   p.X = (const _Float16*)y16; p.Wt = (const _Float16*)w1; p.bias = b1; p.x32 = x32; p.tok16 = nullptr; p.pe = nullptr;
   p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M; p.K = 512;
@@ -465,7 +449,7 @@ extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1, const 
   FP_SET_MAX_LDS((k_linear_ln512<128, 3, true, true>), LDS);
   hipLaunchKernelGGL((k_linear_ln512<128, 3, true, true>), dim3(tiles), dim3(LL_THREADS), LDS, (hipStream_t)stream, p);
   hipLaunchKernelGGL(k_ln_mean_finish, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, gamma, beta, out,
-                     rows_per_group, 128);
+                     rows_per_group);
   FP_CHECK_LAUNCH("fp_ffn_layernorm_mean_fwd");
   return FP_OK;
 }

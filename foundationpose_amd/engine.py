@@ -335,7 +335,7 @@ class _HipEncoderLayer:
         else:
             sa = self.att(x16)                                                   # fp16
             y32, y16 = ops.layernorm_res(sa, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)   # LN(x + sa): fp32 stream + fp16 copy
-        if FUSED_FFN and y16.shape[1] >= 128:
+        if FUSED_FFN and y16.shape[1] % 16 == 0:
             return ops.ffn_layernorm_mean(y16, self.l1.w, self.l1.b, self.l2.w, self.l2.b, y32, self.n2[0], self.n2[1], 1e-5)
         ff = self.l2(self.l1(y16, relu=True))
         return ops.colmean_f16(ff, self.n2[0], self.n2[1], 1e-5, resid32=y32)    # mean_t LN(y + ff)

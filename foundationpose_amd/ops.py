@@ -399,8 +399,9 @@ def ffn_layernorm_mean(y16, w1, b1, w2, b2, x32, gamma, beta, eps=1e-5):
         raise _lib.FpAmdError("ffn_layernorm_mean: d_model must be 512")
     x32 = _dev(x32, torch.float32, "x32")
     out = torch.empty((G_, D), dtype=torch.float32, device=y.device)
-    tiles = (G_ * R + 127) // 128
-    ws = torch.empty((max(tiles, 1), 2, 512), dtype=torch.float32, device=y.device)
+    if R % 16:
+        raise _lib.FpAmdError(f"ffn_layernorm_mean: {R} rows per group, must be a multiple of 16")
+    ws = torch.empty((max(G_ * R // 16, 1), 512), dtype=torch.float32, device=y.device)
     st = _lib.lib().fp_ffn_layernorm_mean_fwd(_ptr(y), _ptr(_dev(w1, torch.float16, "w1")), _ptr(_dev(b1, torch.float32, "b1")),
                                               _ptr(_dev(w2, torch.float16, "w2")), _ptr(_dev(b2, torch.float32, "b2")), _ptr(x32),
                                               _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")), float(eps),

@@ -207,11 +207,12 @@ int fp_linear_layernorm_fwd(const void* x16 /*dev*/, const void* w16 /*dev*/, co
  * token mean that follows it in RefineNet.forward (refine_network.py:90-91, taken before the 512 -> 3|6 head: the mean and that
  * Linear commute):  out[g, :] = mean_{r < rows_per_group} ( LN(x32[row] + f32(linear2(relu(linear1(y16[row]))))) * gamma + beta ),
  * row = g * rows_per_group + r.  = fp_igemm_f16_fwd x 2 + fp_colmean_f16_fwd with neither (M, 512) intermediate reaching HBM:
- * a workgroup owns 128 complete rows through both Linears and the LayerNorm; the token mean is summed per tile and finished in a
- * fixed order (deterministic; another fp32 summation order than fp_colmean_f16_fwd's, so equal to it up to fp32 rounding, not bit
- * for bit).  y16 (M, 512) fp16 = norm1's output, x32 (M, 512) f32 = the residual stream, w1 / w2 (512, 512) fp16 (PyTorch layout),
- * b1 / b2 (512) f32 | NULL, out (groups, 512) f32, M = groups * rows_per_group, rows_per_group >= 128.
- * workspace: ceil(M / 128) * 2 * 512 floats of device scratch owned by the caller. */
+ * a workgroup owns 128 complete rows through both Linears and the LayerNorm; the token mean is summed in chunks of 16
+ * consecutive rows of a group, then over a group's chunks in order -- deterministic, and independent of where in the batch a
+ * group sits (a sub-batch or shard returns the bits of the full batch); another fp32 summation order than fp_colmean_f16_fwd's, so
+ * equal to it up to fp32 rounding, not bit for bit.  y16 (M, 512) fp16 = norm1's output, x32 (M, 512) f32 = the residual stream, w1 / w2 (512, 512) fp16 (PyTorch layout),
+ * b1 / b2 (512) f32 | NULL, out (groups, 512) f32, M = groups * rows_per_group, rows_per_group a multiple of 16.
+ * workspace: M / 16 * 512 floats of device scratch owned by the caller. */
 int fp_ffn_layernorm_mean_fwd(const void* y16 /*dev*/, const void* w1 /*dev*/, const float* b1 /*dev|NULL*/, const void* w2 /*dev*/,
                               const float* b2 /*dev|NULL*/, const float* x32 /*dev*/, const float* gamma /*dev 512*/,
                               const float* beta /*dev 512*/, float eps, float* out /*dev*/, float* workspace /*dev*/,

@@ -634,6 +634,34 @@ def test_linear_layernorm_is_the_two_kernel_path(dev):
             assert only16[0] is None and torch.equal(only16[1], want16)
 
 
+def test_ffn_layernorm_mean_is_the_three_kernel_path_up_to_summation_order(dev):
+    """fp_ffn_layernorm_mean_fwd (linear1 + ReLU + linear2 + residual + norm2 + token mean in one launch) against 2 x fp_igemm_f16_fwd +
+    fp_colmean_f16_fwd: the same rounding points, the token mean summed in another fixed fp32 order -> equal to ~1e-6 of the values; and
+    the order does not depend on where in the batch a hypothesis sits: a slice of the batch returns the bits of the whole batch (what
+    sub-batches on two streams, shards and the single batch rely on)"""
+    from foundationpose_amd import ops
+    from foundationpose_amd.engine import _HipLinear
+    g = torch.Generator(device="cpu").manual_seed(12)
+    l1 = _HipLinear((torch.randn((512, 512), generator=g) * 0.05).to(dev), (torch.randn((512,), generator=g) * 0.1).to(dev))
+    l2 = _HipLinear((torch.randn((512, 512), generator=g) * 0.05).to(dev), (torch.randn((512,), generator=g) * 0.1).to(dev))
+    gamma = (1.0 + 0.1 * torch.randn((512,), generator=g)).to(dev)
+    beta = (0.1 * torch.randn((512,), generator=g)).to(dev)
+    for n, S in ((75, 400), (3, 400), (5, 144), (2, 16)):
+        y16 = torch.randn((n, S, 512), generator=g).to(torch.float16).to(dev)
+        x32 = torch.randn((n, S, 512), generator=g).to(dev)
+        fused = ops.ffn_layernorm_mean(y16, l1.w, l1.b, l2.w, l2.b, x32, gamma, beta, 1e-5)
+        three = ops.colmean_f16(l2(l1(y16, relu=True)), gamma, beta, 1e-5, resid32=x32)
+        assert fused.shape == (n, 512) and torch.isfinite(fused).all()
+        assert (fused - three).abs().max().item() <= 2e-6 * max(1.0, three.abs().max().item()), (n, S)
+        for a, b in ((0, 1), (n // 2, n), (1, n - 1)):
+            if b > a:
+                part = ops.ffn_layernorm_mean(y16[a:b].contiguous(), l1.w, l1.b, l2.w, l2.b, x32[a:b].contiguous(), gamma, beta, 1e-5)
+                assert torch.equal(part, fused[a:b]), (n, S, a, b)
+    with pytest.raises(Exception):
+        ops.ffn_layernorm_mean(torch.zeros((2, 130, 512), dtype=torch.float16, device=dev), l1.w, l1.b, l2.w, l2.b,
+                               torch.zeros((2, 130, 512), device=dev), gamma, beta, 1e-5)
+
+
 def test_replicate_channels(dev):
     """fp_replicate_rows_f16: one image's channel group copied into the same group of the following images, nothing else touched"""
     from foundationpose_amd import ops

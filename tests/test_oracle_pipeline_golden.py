@@ -90,13 +90,25 @@ def test_reference_predictors_one_pass(scene, gold, frame):
     tr = []
     out = op.refine_predict(rcfg, random_state_dict("refine", rcfg, 0), scene["rgb"], frame["depth"], scene["K"], P, frame["xyz"],
                             scene["mesh_np"], scene["diameter"], iteration=1, trace=tr)
-    assert np.abs(out[:, :3, 3] - gold["g4_refined_1it"][:, :3, 3]).max() <= 1e-3
-    assert np.abs(out[:, :3, :3] - gold["g4_refined_1it"][:, :3, :3]).max() <= 5e-3
-    np.testing.assert_allclose(tr[0]["trans"] * np.float32(scene["diameter"] / 2), gold["g4_trans_delta"], atol=1e-3)
+    # measured (round 4, after the rasteriser's tie rule was defined in nvdiffrast's window space and the golden re-minted): 3.0e-6 m,
+    # 1.8e-5 on the rotation entries, 3.0e-6 on the translation delta -- the 1e-3 / 5e-3 band of rounds 1-2 was the stand-in network's
+    # response to a dozen texture-edge pixels that no longer differ (test_one_pass_deviation_is_explained_by_the_rendered_inputs)
+    assert np.abs(out[:, :3, 3] - gold["g4_refined_1it"][:, :3, 3]).max() <= 2e-5
+    assert np.abs(out[:, :3, :3] - gold["g4_refined_1it"][:, :3, :3]).max() <= 1e-4
+    np.testing.assert_allclose(tr[0]["trans"] * np.float32(scene["diameter"] / 2), gold["g4_trans_delta"], atol=2e-5)
     assert np.abs(out[:, :3, 3] - P[:, :3, 3]).max() > 5e-3       # a real update, not a no-op
+    trs = []
     s = op.score_predict(scfg, random_state_dict("score", scfg, 0), scene["rgb"], frame["depth"], scene["K"], P, scene["mesh_np"],
-                         scene["diameter"])
-    np.testing.assert_allclose(s, gold["g4_scores"], atol=0.6)
+                         scene["diameter"], trace=trs)
+    # measured: |score - reference| = 0.44, 0.37, 0.034 on logits of spread (std) 8.9.  The two larger ones are the hypotheses whose
+    # observed crop has nearest-neighbour TIES on its first row (the frame pixel that falls exactly on the window edge: kornia's
+    # stand-in and fp_oracle.c's deterministic rule pick different neighbours there, test_scorer_inputs_match_reference; ~20 of
+    # 25 600 xyz pixels each); the hypothesis without a tie pixel agrees to 0.034.  Gate: 0.05 without ties, 0.6 (7 % of the spread)
+    # with -- the advisor's round-3 question why 0.3 became 0.6: the re-minted golden moved which hypotheses carry ties, not the
+    # arithmetic.
+    ties = (trs[0]["B"][:, 3:, ::2, ::2] != gold["g3_score_B"][:, 3:]).any(1).reshape(len(s), -1).sum(1)
+    dev = np.abs(s - gold["g4_scores"])
+    assert (dev[ties == 0] <= 0.05).all() and (dev <= 0.6).all() and (ties == 0).any() and (ties > 0).any(), (dev, ties)
     assert np.argmax(s) == np.argmax(gold["g4_scores"]) and np.argmin(s) == np.argmin(gold["g4_scores"])
 
 
@@ -127,12 +139,14 @@ def test_one_pass_deviation_is_explained_by_the_rendered_inputs(scene, gold, fra
     assert dB[:, :3].max() < 1e-4 and (dB[:, 3:] > 0).mean() < 2e-3      # observed crop: rgb 3e-5, xyz exact up to edge ties
     assert dA[:, 3:].max() < 5e-4                                        # rendered xyz agrees ...
     n_rgb = int((dA[0, :3].max(axis=0) > 1e-3).sum())
-    assert n_rgb < 0.02 * 160 * 160, n_rgb                     # ... rendered colour: a few hundred texture-edge / silhouette pixels
+    # ... rendered colour: a few hundred texture-edge / silhouette pixels in rounds 1-2 (hence the old `0 < n_rgb` lower bound), NONE
+    # since round 3's tie-rule fix + re-minted golden: the renderers now agree to 1e-3 on every pixel of this hypothesis
+    assert n_rgb < 0.02 * 160 * 160, n_rgb
     # (c) the output deviation of the full pass comes from those pixels
     o_own_in = nets.refine_forward(torch.from_numpy(A), torch.from_numpy(B), sd)
     dev_total = np.abs(o_own_in["rot"].numpy()[0] - gold["g4_raw_rot"][0]).max()
     dev_inputs_only = np.abs(o_own_in["rot"].numpy()[0] - o_ref_in["rot"].numpy()[0]).max()
-    assert abs(dev_total - dev_inputs_only) < 5e-5, (dev_total, dev_inputs_only)
+    assert abs(dev_total - dev_inputs_only) < 5e-5 and dev_total < 1e-4, (dev_total, dev_inputs_only)
     print(f"texture-edge pixels: {n_rgb}, raw rot deviation {dev_total:.2e} (inputs only: {dev_inputs_only:.2e})")
 
 
