@@ -15,6 +15,11 @@ the compute stream, never rings of small messages.  "On the compute stream": a s
 has sync'ed at CPP level") is issued by ProcessGroupNCCL on the CURRENT stream in the PyTorch of this image (2.10), not on
 the group's side stream, so the exchange is ordered like any other kernel of the step and is captured into a hipGraph with
 it (tests/test_gpu_parity.py::test_rccl_all_gather_is_captured_with_the_compute_stream).
+
+A group on the "gloo" backend with device tensors (several ranks sharing one GPU -- RCCL refuses two ranks on one device --
+or a host without RCCL) takes the same two functions: `_all_gather` stages that one buffer through host memory.  Only the
+collective changes; it is how tests/test_gpu_parity.py runs two REAL ranks (real predictors, real rendezvous, a real
+inter-process all-gather) on the single GPU of the test box.
 """
 import torch
 import torch.distributed as dist
@@ -30,6 +35,16 @@ def _world(group):
     if not (dist.is_available() and dist.is_initialized()):
         return 1, 0
     return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _all_gather(out, send, group=None):
+    """the all-gather of this module: RCCL on the current stream; on a gloo group with device tensors, through host memory"""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        out.copy_(host)
+        return
+    dist.all_gather_into_tensor(out, send, group=group)
 
 
 def all_gather_rows(local, n_total, group=None, collective=None, world_rank=None):
@@ -57,7 +72,7 @@ def all_gather_rows(local, n_total, group=None, collective=None, world_rank=None
     if collective is not None:
         collective(out, send)
     else:
-        dist.all_gather_into_tensor(out, send, group=group)
+        _all_gather(out, send, group)
     if world * chunk == n_total:
         return out
     return torch.cat([out[r * chunk:r * chunk + (be - bb)] for r, (bb, be) in enumerate(bounds)], dim=0)
@@ -111,5 +126,5 @@ def gather_object_records(scores, poses, group=None):
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return rec[None]
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out, rec, group=group)  # concatenated along dim 0 (same form on RCCL and gloo)
+    _all_gather(out, rec, group)  # concatenated along dim 0 (same form on RCCL and gloo)
     return out.reshape(world, rec.shape[0], rec.shape[1])

@@ -1042,6 +1042,94 @@ def test_rccl_all_gather_is_captured_with_the_compute_stream(dev):
     assert r.returncode == 0 and "RCCL_CAPTURE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+_TWO_RANKS = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+root, port, rank, world, fin, fout = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
+sys.path.insert(0, root)
+from foundationpose_amd import dist as fpd
+from foundationpose_amd.Utils import make_mesh_tensors
+from foundationpose_amd.mesh import make_can_mesh
+from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+from foundationpose_amd.predict_score import ScorePredictor
+from foundationpose_amd.weights import CONTRACTION_HEAD_SCALE, DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = port
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+z = np.load(fin)
+mesh = make_can_mesh(); gm = make_mesh_tensors(mesh, device=dev)
+rcfg, scfg = dict(DEFAULT_REFINE_CFG), dict(DEFAULT_SCORE_CFG)
+refiner = PoseRefinePredictor(cfg=rcfg, state_dict=random_state_dict("refine", rcfg, 0, head_scale=CONTRACTION_HEAD_SCALE), device=dev)
+scorer = ScorePredictor(cfg=scfg, state_dict=random_state_dict("score", scfg, 0), device=dev)
+t = lambda k: torch.as_tensor(z[k], device=dev)
+poses, scores, order = fpd.register_hypothesis_parallel(refiner, scorer, t("rgb"), t("depth"), z["K"], t("poses"), t("xyz"), mesh=mesh,
+                                                        mesh_tensors=gm, mesh_diameter=float(z["diameter"]), iteration=int(z["iteration"]))
+rec = fpd.gather_object_records(scores + rank, poses)          # the object-parallel exchange, on device tensors over gloo
+torch.cuda.synchronize()
+np.savez(fout, poses=poses.cpu().numpy(), scores=scores.cpu().numpy(), order=order.cpu().numpy(), rec=rec.cpu().numpy())
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+@pytest.mark.parametrize("n", [252, 61])
+def test_two_real_ranks_on_one_gpu_rank_like_one_batch(scene, dev, gmesh, frame, tmp_path, n):
+    """SURVEY 8(e) with nothing emulated but the wire: TWO processes (torch.distributed rendezvous on 127.0.0.1, world size 2)
+    share the box's one GPU, each with the real PoseRefinePredictor / ScorePredictor on its shard of the hypotheses (126 + 126, and
+    the ragged 31 + 30), exchanging the [feature | pose] records with a real inter-process all-gather -- gloo through host memory,
+    because RCCL refuses two ranks on one device (dist._all_gather); RCCL itself has only run at world size 1 here.  Both ranks
+    must return the same bits, and those must rank the hypotheses like the single batch of this process."""
+    import socket
+    import subprocess
+    import sys
+    from foundationpose_amd import dist as fpd
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import CONTRACTION_HEAD_SCALE, DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    from amp_util import kendall_tau
+    it = 3
+    fin = str(tmp_path / "in.npz")
+    np.savez(fin, rgb=frame["rgb_t"].cpu().numpy(), depth=frame["depth_f"], xyz=frame["xyz"], K=scene["K"], poses=scene["poses"][:n],
+             diameter=scene["diameter"], iteration=it)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    outs = [str(tmp_path / f"out{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANKS, ROOT, str(port), str(r), "2", fin, outs[r]], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    # meanwhile: the single batch, in this process
+    rcfg, scfg = dict(DEFAULT_REFINE_CFG), dict(DEFAULT_SCORE_CFG)
+    refiner = PoseRefinePredictor(cfg=rcfg, state_dict=random_state_dict("refine", rcfg, 0, head_scale=CONTRACTION_HEAD_SCALE), device=dev)
+    scorer = ScorePredictor(cfg=scfg, state_dict=random_state_dict("score", scfg, 0), device=dev)
+    poses1, scores1, order1 = fpd.register_hypothesis_parallel(
+        refiner, scorer, frame["rgb_t"], frame["depth_t"], scene["K"], torch.as_tensor(scene["poses"][:n], device=dev), frame["xyz_t"],
+        mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"], iteration=it)
+    for r, p in enumerate(procs):
+        so_, se_ = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"RANK_OK {r}" in so_, (r, so_[-2000:], se_[-4000:])
+    z = [np.load(o) for o in outs]
+    for k in ("poses", "scores", "order"):
+        assert np.array_equal(z[0][k], z[1][k]), f"{k} differs between the two ranks"              # replicated
+    for r in range(2):                                                                             # object-parallel records
+        assert z[r]["rec"].shape == (2, n, 17)
+        assert np.allclose(z[r]["rec"][1, :, 0] - 1, z[r]["rec"][0, :, 0], atol=1e-4)          # row g = rank g's record
+        assert np.array_equal(z[r]["rec"][0, :, 1:].reshape(n, 4, 4), z[0]["poses"])
+    s1 = np.empty(n, np.float32); s1[order1.cpu().numpy()] = scores1.cpu().numpy()
+    s2 = np.empty(n, np.float32); s2[z[0]["order"]] = z[0]["scores"]
+    p1 = np.empty((n, 4, 4), np.float32); p1[order1.cpu().numpy()] = poses1.cpu().numpy()
+    p2 = np.empty((n, 4, 4), np.float32); p2[z[0]["order"]] = z[0]["poses"]
+    dt = float(np.linalg.norm(p1[:, :3, 3] - p2[:, :3, 3], axis=1).max())
+    dR = float(_geodesic(p1[:, :3, :3], p2[:, :3, :3]).max())
+    tau = kendall_tau(s1, s2)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"two_ranks_one_gpu_n{n}.json"), "w") as f:
+        json.dump(dict(n=n, iterations=it, poses_bit_identical_to_single_batch=bool(np.array_equal(p1, p2)),
+                       scores_bit_identical_to_single_batch=bool(np.array_equal(s1, s2)), max_dt=dt, max_dR=dR, kendall_tau=tau,
+                       max_abs_score_diff=float(np.abs(s1 - s2).max())), f)
+    assert dt <= 1e-4 and dR <= 1e-4, (dt, dR)
+    assert tau >= 0.98 and int(np.argmax(s1)) == int(np.argmax(s2)), tau
+
+
 def test_network_kernels_write_only_their_outputs(dev):
     """outputs placed inside a poisoned arena: ragged GEMM / conv shapes (partial tiles), tokens + positional output,
     attention -- no byte outside the output tensors changes"""
