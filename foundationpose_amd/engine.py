@@ -325,18 +325,20 @@ class _HipEncoderLayer:
         self.l2 = _HipLinear(sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
         self.n1 = (sd[p + ".norm1.weight"].float().contiguous(), sd[p + ".norm1.bias"].float().contiguous())
         self.n2 = (sd[p + ".norm2.weight"].float().contiguous(), sd[p + ".norm2.bias"].float().contiguous())
+        # fragment-packed copies for the row-owning fused kernels (csrc/linear_ln.hip), which read weights from L2 into registers
+        self.out_p, self.l1_p, self.l2_p = (ops.PackedLinear512(m.w) for m in (self.att.out, self.l1, self.l2))
 
     def pooled(self, tok16, x16, pe):
         """-> mean over the tokens of the layer output, (N, 512) fp32"""
         if FUSED_OUT_PROJ_LN:
             # out_proj + residual + norm1 in one launch, the projection staying on chip (fp_linear_layernorm_fwd): the same bits
-            y32, y16 = ops.linear_layernorm_res(self.att.context(x16), self.att.out.w, self.att.out.b, self.n1[0], self.n1[1], 1e-5,
+            y32, y16 = ops.linear_layernorm_res(self.att.context(x16), self.out_p, self.att.out.b, self.n1[0], self.n1[1], 1e-5,
                                                 tok16=tok16, pe=pe)
         else:
             sa = self.att(x16)                                                   # fp16
             y32, y16 = ops.layernorm_res(sa, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)   # LN(x + sa): fp32 stream + fp16 copy
         if FUSED_FFN and y16.shape[1] % 16 == 0:
-            return ops.ffn_layernorm_mean(y16, self.l1.w, self.l1.b, self.l2.w, self.l2.b, y32, self.n2[0], self.n2[1], 1e-5)
+            return ops.ffn_layernorm_mean(y16, self.l1_p, self.l1.b, self.l2_p, self.l2.b, y32, self.n2[0], self.n2[1], 1e-5)
         ff = self.l2(self.l1(y16, relu=True))
         return ops.colmean_f16(ff, self.n2[0], self.n2[1], 1e-5, resid32=y32)    # mean_t LN(y + ff)
 

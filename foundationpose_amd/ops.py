@@ -367,15 +367,34 @@ def layernorm_res(branch16, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None
     return y32, y16
 
 
-def linear_layernorm_res(x16, w16, bias, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None, want32=True, want16=True):
-    """layernorm_res(f16(x16 @ w16^T + bias), ...) in ONE launch, the product staying on chip (fp_linear_layernorm_fwd).
-    x16 (..., K) fp16, w16 (512, K) fp16 -> (y32 | None, y16 | None) of shape (..., 512); bit-identical to the two-kernel path"""
+class PackedLinear512:
+    """fragment-packed copy of a (512, 512) fp16 nn.Linear weight (fp_pack_linear512_f16): what linear_layernorm_res and
+    ffn_layernorm_mean take, whose waves read their weight rows straight from L2 into MFMA operand registers"""
+
+    def __init__(self, w16):
+        w = _dev(w16, torch.float16, "w16")
+        if tuple(w.shape) != (512, 512):
+            raise _lib.FpAmdError(f"PackedLinear512: weight {tuple(w.shape)}, must be (512, 512)")
+        self.data = torch.empty_like(w)
+        _lib.check(_lib.lib().fp_pack_linear512_f16(_ptr(w), _ptr(self.data), _stream(w)), "fp_pack_linear512_f16")
+
+
+def _packed(w, name):
+    if not isinstance(w, PackedLinear512):
+        raise _lib.FpAmdError(f"{name}: the weight must be a PackedLinear512 (ops.PackedLinear512(w16))")
+    return w.data
+
+
+def linear_layernorm_res(x16, w_packed, bias, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None, want32=True, want16=True):
+    """layernorm_res(f16(x16 @ w^T + bias), ...) in ONE launch, the product staying on chip (fp_linear_layernorm_fwd).
+    x16 (..., 512) fp16, w_packed = PackedLinear512 of the (512, 512) weight -> (y32 | None, y16 | None) of shape (..., 512);
+    bit-identical to the two-kernel path"""
     x = _dev(x16, torch.float16, "x16")
-    w = _dev(w16, torch.float16, "w16")
+    w = _packed(w_packed, "linear_layernorm_res")
     K = int(x.shape[-1])
-    D = int(w.shape[0])
-    if w.dim() != 2 or int(w.shape[1]) != K:
-        raise _lib.FpAmdError(f"linear_layernorm_res: w16 {tuple(w.shape)} does not match x16 (..., {K})")
+    D = 512
+    if K != 512:
+        raise _lib.FpAmdError(f"linear_layernorm_res: x16 (..., {K}), must be (..., 512)")
     M = x.numel() // K
     x32 = _dev(x32, torch.float32, "x32"); tok16 = _dev(tok16, torch.float16, "tok16"); pe = _dev(pe, torch.float32, "pe")
     S = int(pe.shape[-2]) if pe is not None else 0
@@ -389,10 +408,11 @@ def linear_layernorm_res(x16, w16, bias, gamma, beta, eps=1e-5, x32=None, tok16=
     return y32, y16
 
 
-def ffn_layernorm_mean(y16, w1, b1, w2, b2, x32, gamma, beta, eps=1e-5):
+def ffn_layernorm_mean(y16, w1_packed, b1, w2_packed, b2, x32, gamma, beta, eps=1e-5):
     """(G, R, 512) fp16 y16 (norm1's output) + (G, R, 512) f32 residual stream -> (G, 512) f32 =
     mean_r LN(x32 + linear2(relu(linear1(y16)))) * gamma + beta, one launch + a finish kernel (fp_ffn_layernorm_mean_fwd):
-    the feed-forward half of the encoder layer and the token mean with both (G*R, 512) intermediates staying on chip"""
+    the feed-forward half of the encoder layer and the token mean with both (G*R, 512) intermediates staying on chip;
+    w1_packed / w2_packed: PackedLinear512 of the two (512, 512) weights"""
     y = _dev(y16, torch.float16, "y16")
     G_, R, D = (int(v) for v in y.shape)
     if D != 512:
@@ -402,8 +422,8 @@ def ffn_layernorm_mean(y16, w1, b1, w2, b2, x32, gamma, beta, eps=1e-5):
     if R % 16:
         raise _lib.FpAmdError(f"ffn_layernorm_mean: {R} rows per group, must be a multiple of 16")
     ws = torch.empty((max(G_ * R // 16, 1), 512), dtype=torch.float32, device=y.device)
-    st = _lib.lib().fp_ffn_layernorm_mean_fwd(_ptr(y), _ptr(_dev(w1, torch.float16, "w1")), _ptr(_dev(b1, torch.float32, "b1")),
-                                              _ptr(_dev(w2, torch.float16, "w2")), _ptr(_dev(b2, torch.float32, "b2")), _ptr(x32),
+    st = _lib.lib().fp_ffn_layernorm_mean_fwd(_ptr(y), _ptr(_packed(w1_packed, "ffn_layernorm_mean")), _ptr(_dev(b1, torch.float32, "b1")),
+                                              _ptr(_packed(w2_packed, "ffn_layernorm_mean")), _ptr(_dev(b2, torch.float32, "b2")), _ptr(x32),
                                               _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")), float(eps),
                                               _ptr(out), _ptr(ws), ws.numel() * 4, G_, R, _stream(y))
     _lib.check(st, "fp_ffn_layernorm_mean_fwd")
@@ -577,12 +597,12 @@ layernorm_res = _timed("fp_layernorm_res_fwd", layernorm_res,
                        lambda br, *a, **k: ((2.0 + (4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
                                              + (2.0 if k.get("want16", True) else 0.0)) * br.numel(), 0.0))
 linear_layernorm_res = _timed("fp_linear_layernorm_fwd", linear_layernorm_res,
-                              lambda x, w, *a, **k: (2.0 * x.numel() + 2.0 * w.numel() + (x.numel() // x.shape[-1]) * w.shape[0] *
+                              lambda x, w, *a, **k: (2.0 * x.numel() + 2.0 * 512 * 512 + (x.numel() // x.shape[-1]) * 512 *
                                                      ((4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
                                                       + (2.0 if k.get("want16", True) else 0.0)),
-                                                     2.0 * x.numel() * w.shape[0]))
+                                                     2.0 * x.numel() * 512))
 ffn_layernorm_mean = _timed("fp_ffn_layernorm_mean_fwd", ffn_layernorm_mean,
-                            lambda y, w1, b1, w2, *a, **k: (6.0 * y.numel() + 2.0 * (w1.numel() + w2.numel()), 4.0 * y.numel() * 512))
+                            lambda y, w1, b1, w2, *a, **k: (6.0 * y.numel() + 4.0 * 512 * 512, 4.0 * y.numel() * 512))
 colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16,
                      lambda x, *a, **k: ((6.0 if k.get("resid32") is not None else 2.0) * x.numel(), 0.0))
 rows_linear = _timed("fp_rows_linear_fwd", rows_linear)

@@ -192,12 +192,21 @@ int fp_layernorm_res_fwd(const float* x32 /*dev|NULL*/, const void* tok16 /*dev|
                          const void* branch16 /*dev*/, const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps,
                          float* y32 /*dev|NULL*/, void* y16 /*dev|NULL*/, int M, int D, void* stream);
 
-/* A 512-wide nn.Linear of the encoder layer (refine_network.py:56-70: self_attn.out_proj or linear2, under autocast: fp16
+/* Fragment-packed copy of a (512, 512) fp16 weight matrix W[out][in] (nn.Linear layout) for fp_linear_layernorm_fwd and
+ * fp_ffn_layernorm_mean_fwd, whose waves read their weight rows straight from L2 into MFMA operand registers: for channel group
+ * w = out / 64, k16-step q = in / 16, channel tile i = (out / 32) % 2 the 64 lanes' operands stand back to back,
+ *   packed[((w * 32 + q) * 2 + i) * 64 + lane][0..7] = W[64 w + 32 i + (lane & 31)][16 q + 8 (lane >> 5) + 0..7],
+ * so a wave load is one contiguous KiB (the row-per-lane form of the same load is served at one lane per clock by the vector
+ * cache).  Same size as the matrix; done once per weight matrix; `packed` must not alias `w16`. */
+int fp_pack_linear512_f16(const void* w16 /*dev*/, void* packed /*dev*/, void* stream);
+
+/* A 512 -> 512 nn.Linear of the encoder layer (refine_network.py:56-70: self_attn.out_proj or linear2, under autocast: fp16
  * operands, fp32 accumulation + bias, one rounding to fp16) fused with the residual add and the LayerNorm that consume it:
  * fp_igemm_f16_fwd (taps = 1, N = 512) followed by fp_layernorm_res_fwd with branch16 = that product, in one launch and
  * without the (M, 512) product reaching HBM; per element the same instruction sequence, i.e. the same bits.
- * x16 (M, K) fp16, w16 (512, K) fp16 (PyTorch layout), bias (512) f32 | NULL; the other arguments as fp_layernorm_res_fwd. */
-int fp_linear_layernorm_fwd(const void* x16 /*dev*/, const void* w16 /*dev*/, const float* bias /*dev|NULL*/,
+ * x16 (M, 512) fp16, w16_packed = fp_pack_linear512_f16 of the (512, 512) weight, bias (512) f32 | NULL; K and D must be 512 (the
+ * 128 x K A tile of a workgroup lives in LDS whole); the other arguments as fp_layernorm_res_fwd. */
+int fp_linear_layernorm_fwd(const void* x16 /*dev*/, const void* w16_packed /*dev*/, const float* bias /*dev|NULL*/,
                             const float* x32 /*dev|NULL*/, const void* tok16 /*dev|NULL*/, const float* pe /*dev|NULL*/, int S,
                             const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps, float* y32 /*dev|NULL*/,
                             void* y16 /*dev|NULL*/, int M, int K, int D, void* stream);
@@ -210,13 +219,14 @@ int fp_linear_layernorm_fwd(const void* x16 /*dev*/, const void* w16 /*dev*/, co
  * a workgroup owns 128 complete rows through both Linears and the LayerNorm; the token mean is summed in chunks of 16
  * consecutive rows of a group, then over a group's chunks in order -- deterministic, and independent of where in the batch a
  * group sits (a sub-batch or shard returns the bits of the full batch); another fp32 summation order than fp_colmean_f16_fwd's, so
- * equal to it up to fp32 rounding, not bit for bit.  y16 (M, 512) fp16 = norm1's output, x32 (M, 512) f32 = the residual stream, w1 / w2 (512, 512) fp16 (PyTorch layout),
- * b1 / b2 (512) f32 | NULL, out (groups, 512) f32, M = groups * rows_per_group, rows_per_group a multiple of 16.
+ * equal to it up to fp32 rounding, not bit for bit.  y16 (M, 512) fp16 = norm1's output, x32 (M, 512) f32 = the residual stream,
+ * w1_packed / w2_packed = fp_pack_linear512_f16 of the (512, 512) fp16 weights, b1 / b2 (512) f32 | NULL, out (groups, 512) f32,
+ * M = groups * rows_per_group, rows_per_group a multiple of 16.
  * workspace: M / 16 * 512 floats of device scratch owned by the caller. */
-int fp_ffn_layernorm_mean_fwd(const void* y16 /*dev*/, const void* w1 /*dev*/, const float* b1 /*dev|NULL*/, const void* w2 /*dev*/,
-                              const float* b2 /*dev|NULL*/, const float* x32 /*dev*/, const float* gamma /*dev 512*/,
-                              const float* beta /*dev 512*/, float eps, float* out /*dev*/, float* workspace /*dev*/,
-                              size_t workspace_bytes, int groups, int rows_per_group, void* stream);
+int fp_ffn_layernorm_mean_fwd(const void* y16 /*dev*/, const void* w1_packed /*dev*/, const float* b1 /*dev|NULL*/,
+                              const void* w2_packed /*dev*/, const float* b2 /*dev|NULL*/, const float* x32 /*dev*/,
+                              const float* gamma /*dev 512*/, const float* beta /*dev 512*/, float eps, float* out /*dev*/,
+                              float* workspace /*dev*/, size_t workspace_bytes, int groups, int rows_per_group, void* stream);
 
 /* `.mean(dim=1)` over the tokens of each hypothesis (refine_network.py:90-91, score_network.py:74), optionally fused
  * with the residual add + LayerNorm that precede it: out[g, :] = mean_{r < rows_per_group} f(row g*rows_per_group + r),

@@ -59,8 +59,10 @@ def test_argument_errors_are_reported_without_gpu():
                                     C.c_void_p(16), None, 4, 512, None) == -1     # residual given twice
     assert lib.fp_attention_f16_fwd(C.c_void_p(16), C.c_void_p(16), 1, 4, 4, 128, 2, None) == -1
     assert lib.fp_linear_layernorm_fwd(C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16),
-                                       C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 500, 512, None) == -1         # K % 32
-    assert b"multiple of 32" in lib.fp_last_error()
+                                       C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 256, 512, None) == -1         # K != 512
+    assert b"K=256" in lib.fp_last_error()
+    assert lib.fp_pack_linear512_f16(C.c_void_p(16), C.c_void_p(16), None) == -1                                   # in place
+    assert lib.fp_pack_linear512_f16(None, C.c_void_p(16), None) == -1
     assert lib.fp_linear_layernorm_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400,
                                        C.c_void_p(16), C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 512, 512, None) == -1   # residual twice
     assert lib.fp_replicate_rows_f16(C.c_void_p(16), C.c_void_p(32), 3, 10, 100, 256, 256, 2560, None) == -1      # 100 channels

@@ -617,10 +617,17 @@ def test_linear_layernorm_is_the_two_kernel_path(dev):
     w = (torch.randn((512, 512), generator=g) * 0.05)
     b = torch.randn((512,), generator=g) * 0.1
     lin = _HipLinear(w.to(dev), b.to(dev))
+    wp = ops.PackedLinear512(lin.w)                       # what the fused kernel reads: the fragment-packed copy
+    # the packing itself: lane l of k16-step q, channel tile i of channel group c holds W[64 c + 32 i + (l & 31)][16 q + 8 (l >> 5) ..+8]
+    ref = lin.w.reshape(8, 2, 32, 32, 2, 8).permute(0, 3, 1, 4, 2, 5).contiguous()      # [c, q, i, l >> 5, l & 31, 8]
+    assert torch.equal(wp.data.reshape(-1), ref.reshape(-1))
+    with pytest.raises(Exception):
+        ops.linear_layernorm_res(torch.zeros((4, 512), dtype=torch.float16, device=dev), lin.w, lin.b, torch.ones(512, device=dev),
+                                 torch.zeros(512, device=dev), x32=torch.zeros((4, 512), device=dev))     # an unpacked weight is refused
     gamma = (1.0 + 0.1 * torch.randn((512,), generator=g)).to(dev)
     beta = (0.1 * torch.randn((512,), generator=g)).to(dev)
     pe = torch.randn((400, 512), generator=g).to(dev)
-    for n_seq, S in ((126, 400), (3, 400), (1, 77)):
+    for n_seq, S in ((126, 400), (3, 400), (1, 77), (1, 1), (2, 129)):
         M = n_seq * S
         x = torch.randn((n_seq, S, 512), generator=g).to(torch.float16).to(dev)
         tok = torch.randn((n_seq, S, 512), generator=g).to(torch.float16).to(dev)
@@ -628,9 +635,9 @@ def test_linear_layernorm_is_the_two_kernel_path(dev):
         for kw in (dict(tok16=tok, pe=pe[:S].contiguous()), dict(x32=x32)):
             br = lin(x)
             want32, want16 = ops.layernorm_res(br, gamma, beta, 1e-5, **kw)
-            got32, got16 = ops.linear_layernorm_res(x, lin.w, lin.b, gamma, beta, 1e-5, **kw)
+            got32, got16 = ops.linear_layernorm_res(x, wp, lin.b, gamma, beta, 1e-5, **kw)
             assert torch.equal(got32, want32) and torch.equal(got16, want16), (M, list(kw))
-            only16 = ops.linear_layernorm_res(x, lin.w, lin.b, gamma, beta, 1e-5, want32=False, **kw)
+            only16 = ops.linear_layernorm_res(x, wp, lin.b, gamma, beta, 1e-5, want32=False, **kw)
             assert only16[0] is None and torch.equal(only16[1], want16)
 
 
@@ -644,21 +651,22 @@ def test_ffn_layernorm_mean_is_the_three_kernel_path_up_to_summation_order(dev):
     g = torch.Generator(device="cpu").manual_seed(12)
     l1 = _HipLinear((torch.randn((512, 512), generator=g) * 0.05).to(dev), (torch.randn((512,), generator=g) * 0.1).to(dev))
     l2 = _HipLinear((torch.randn((512, 512), generator=g) * 0.05).to(dev), (torch.randn((512,), generator=g) * 0.1).to(dev))
+    p1, p2 = ops.PackedLinear512(l1.w), ops.PackedLinear512(l2.w)
     gamma = (1.0 + 0.1 * torch.randn((512,), generator=g)).to(dev)
     beta = (0.1 * torch.randn((512,), generator=g)).to(dev)
     for n, S in ((75, 400), (3, 400), (5, 144), (2, 16)):
         y16 = torch.randn((n, S, 512), generator=g).to(torch.float16).to(dev)
         x32 = torch.randn((n, S, 512), generator=g).to(dev)
-        fused = ops.ffn_layernorm_mean(y16, l1.w, l1.b, l2.w, l2.b, x32, gamma, beta, 1e-5)
+        fused = ops.ffn_layernorm_mean(y16, p1, l1.b, p2, l2.b, x32, gamma, beta, 1e-5)
         three = ops.colmean_f16(l2(l1(y16, relu=True)), gamma, beta, 1e-5, resid32=x32)
         assert fused.shape == (n, 512) and torch.isfinite(fused).all()
         assert (fused - three).abs().max().item() <= 2e-6 * max(1.0, three.abs().max().item()), (n, S)
         for a, b in ((0, 1), (n // 2, n), (1, n - 1)):
             if b > a:
-                part = ops.ffn_layernorm_mean(y16[a:b].contiguous(), l1.w, l1.b, l2.w, l2.b, x32[a:b].contiguous(), gamma, beta, 1e-5)
+                part = ops.ffn_layernorm_mean(y16[a:b].contiguous(), p1, l1.b, p2, l2.b, x32[a:b].contiguous(), gamma, beta, 1e-5)
                 assert torch.equal(part, fused[a:b]), (n, S, a, b)
     with pytest.raises(Exception):
-        ops.ffn_layernorm_mean(torch.zeros((2, 130, 512), dtype=torch.float16, device=dev), l1.w, l1.b, l2.w, l2.b,
+        ops.ffn_layernorm_mean(torch.zeros((2, 130, 512), dtype=torch.float16, device=dev), p1, l1.b, p2, l2.b,
                                torch.zeros((2, 130, 512), device=dev), gamma, beta, 1e-5)
 
 
