@@ -1,4 +1,4 @@
-"""phase timers of k_linear_ln512 (profiling build): first loop incl. cold start / park + second loop (FFN form) / park of the output /
+"""phase timers of k_rows512 (csrc/linear_ln.hip, profiling build): first loop incl. cold start / park + second loop (FFN form) / park of the output /
 LayerNorm rows, per workgroup, 100 MHz wall clock, wave 0
     FP_AMD_LIB=foundationpose_amd/csrc/libfp_amd_profile.so python scripts/dbg_linear_ln.py"""
 import ctypes as C
