@@ -40,7 +40,7 @@ SCORE_GFLOP_CROSS_252 = 0.659
 STEM_GFLOP_PER_IMAGE = (80 * 80 * 64 * 6 * 49 + 40 * 40 * 128 * 64 * 9 + 4 * 40 * 40 * 128 * 128 * 9) * 2 / 1e9   # encodeA, one 160x160 image
 # roofline that bounds each hand-written kernel (DESIGN.md "Kernels")
 KERNEL_BOUND = {"fp_render_crops": "hbm", "fp_warp_crops": "hbm", "fp_conv7x7s2_bn_relu_fwd": "hbm",
-                "fp_igemm_f16_fwd": "mfma", "fp_linear_layernorm_fwd": "mfma", "fp_ffn_layernorm_mean_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
+                "fp_igemm_f16_fwd": "mfma", "fp_linear512_f16_fwd": "mfma", "fp_linear_layernorm_fwd": "mfma", "fp_ffn_layernorm_mean_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
                 "fp_colmean_f16_fwd": "hbm", "fp_attention_f16_fwd": "mfma"}
 
 

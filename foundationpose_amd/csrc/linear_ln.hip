@@ -186,17 +186,19 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
 
   // A fragment addressing inside a block: lane reads row (lane & 31) of a 32-row tile, logical chunk 2 kk + (lane >> 5)
   const int frow = lane & 31, fhalf = lane >> 5;
-  int a_off[LL_TM][LL_KK];
+  // (ll_swz ignores the row tile: 32 t does not reach bits 2-3 of the row; the 128 KiB of blocks need two base registers per kk,
+  // everything else is an immediate offset of the read: ks % 8 blocks and the row tile)
+  const unsigned char* a_ptr[2][LL_KK];
 #pragma unroll
-  for (int t = 0; t < LL_TM; ++t) {
-    const int ra = t * 32 + frow;
-#pragma unroll
-    for (int kk = 0; kk < LL_KK; ++kk) a_off[t][kk] = ra * LL_ROWB + (((2 * kk + fhalf) ^ ll_swz(ra)) << 4);
+  for (int kk = 0; kk < LL_KK; ++kk) {
+    a_ptr[0][kk] = smem + frow * LL_ROWB + (((2 * kk + fhalf) ^ ll_swz(frow)) << 4);
+    a_ptr[1][kk] = a_ptr[0][kk] + 8 * LL_A_BLOCK;
   }
   half8 fa[2][LL_TM];
   auto read_a = [&](int ks, int kk, int slot) {
 #pragma unroll
-    for (int t = 0; t < LL_TM; ++t) fa[slot][t] = *reinterpret_cast<const half8*>(smem + ks * LL_A_BLOCK + a_off[t][kk]);
+    for (int t = 0; t < LL_TM; ++t)
+      fa[slot][t] = *reinterpret_cast<const half8*>(a_ptr[ks >> 3][kk] + (ks & 7) * LL_A_BLOCK + t * 32 * LL_ROWB);
   };
   auto mfma_group = [&](int wslot, int kk, int aslot) {
 #pragma unroll
@@ -412,6 +414,183 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
 #endif
 }
 
+// ---- fp_linear512_f16_fwd: y16 = f16(x16 @ W^T + b) for K = 512 and N = 512 n (the in_proj of nn.MultiheadAttention: N = 1536) on the
+// same operand paths: the workgroup's 128 x 512 A tile is fetched ONCE and stays in LDS while the N / 512 column blocks are
+// computed one after the other (a wave: channels [64 w, +64) of the block), weights from the fragment-packed copy straight into
+// registers.  The first block runs the first loop of k_rows512 (A blocks arriving, one barrier per k-step), the others find the
+// tile complete: no barrier.  Epilogue without the 128 KiB tile (the A tile keeps LDS): each 32 x 32 accumulator tile goes
+// through a wave-private 2 KiB buffer and leaves as 64-byte row pieces (4 consecutive lanes per row).
+struct Linear512Params {
+  const _Float16* X;      // (M, 512)
+  const _Float16* Wp;     // N / 512 fragment-packed (512, 512) blocks back to back
+  const float* bias;      // (N) or null
+  _Float16* Y;            // (M, N)
+  int M, N, relu;
+};
+constexpr int L5_XBUF = 32 * 64;                                   // a wave's transposition buffer: 32 rows x 32 channels fp16
+constexpr int L5_BIAS_OFF = LL_E_BYTES + LL_NW * L5_XBUF;          // bias vector (N floats) behind the eight buffers
+constexpr int L5_MAX_N = 2048;
+constexpr int l5_lds(int N) { return L5_BIAS_OFF + N * 4; }
+static_assert(l5_lds(L5_MAX_N) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+
+__global__ __launch_bounds__(LL_THREADS, 1) void k_linear512(Linear512Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* bias_lds = reinterpret_cast<float*>(smem + L5_BIAS_OFF);
+  unsigned char* xbuf = smem + LL_E_BYTES + wid * L5_XBUF;
+  const int m0 = blockIdx.x * LL_BM;
+  const int nblk = p.N / LL_BN;
+
+  // bias -> LDS: N / 256 pieces of 1 KiB, one LDS-DMA each (waves 0 .. N / 256 - 1; oldest vector-memory operation of the wave)
+  if (wid < p.N / 256) {
+    float* dst = bias_lds + wid * 256;
+    if (p.bias) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
+      ll_dma16(rs, dst, lane * 16, wid * 1024);
+    } else {
+      *reinterpret_cast<float4_*>(dst + lane * 4) = float4_{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  unsigned aoff32;
+  {
+    const int row = wid * 16 + lane / 4;
+    const int c = (lane % 4) ^ ll_swz(row);
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    aoff32 = (unsigned)(((size_t)m * LL_K + c * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.X), 0, 0x7FFFFFFF, 0x00020000);
+  auto request_a = [&](int ks) { ll_dma16(rsA, smem + ks * LL_A_BLOCK + wid * 1024, (int)aoff32, ks * (LL_BK * 2)); };
+  half8 wr[LL_LW + 1][LL_KK][2];
+  auto request_w = [&](const _Float16* wp, int ks, int slot) {
+    const _Float16* src = wp + ((size_t)wid * (LL_K / 16) + ks * LL_KK) * 1024 + lane * 8;
+#pragma unroll
+    for (int kk = 0; kk < LL_KK; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wr[slot][kk][i] = *reinterpret_cast<const half8*>(src + (kk * 2 + i) * 512);
+  };
+  float16_ acc[2][LL_TM];
+  const int frow = lane & 31, fhalf = lane >> 5;
+  // (ll_swz ignores the row tile: 32 t does not reach bits 2-3 of the row; the 128 KiB of blocks need two base registers per kk,
+  // everything else is an immediate offset of the read: ks % 8 blocks and the row tile)
+  const unsigned char* a_ptr[2][LL_KK];
+#pragma unroll
+  for (int kk = 0; kk < LL_KK; ++kk) {
+    a_ptr[0][kk] = smem + frow * LL_ROWB + (((2 * kk + fhalf) ^ ll_swz(frow)) << 4);
+    a_ptr[1][kk] = a_ptr[0][kk] + 8 * LL_A_BLOCK;
+  }
+  half8 fa[2][LL_TM];
+  auto read_a = [&](int ks, int kk, int slot) {
+#pragma unroll
+    for (int t = 0; t < LL_TM; ++t)
+      fa[slot][t] = *reinterpret_cast<const half8*>(a_ptr[ks >> 3][kk] + (ks & 7) * LL_A_BLOCK + t * 32 * LL_ROWB);
+  };
+  auto mfma_group = [&](int wslot, int kk, int aslot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < LL_TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[wslot][kk][i], fa[aslot][j], acc[i][j], 0, 0, 0);
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < LL_TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+  // f16(acc + bias) of column block nb -> Y, tile by tile through the wave's buffer.  D[i = channel][j = row]: a lane holds row
+  // (lane & 31) of a row tile and channels 8 g + 4 (lane >> 5) + {0..3} of a channel tile, g = register >> 2
+  auto store_block = [&](int nb) {
+    const half4 zero4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nl = nb * LL_BN + wid * 64 + i * 32;                 // first channel of the tile
+#pragma unroll
+      for (int j = 0; j < LL_TM; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4_ bv = *reinterpret_cast<const float4_*>(bias_lds + nl + 8 * g + 4 * fhalf);
+          half4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
+          if (p.relu) v = __builtin_elementwise_max(v, zero4);
+          *reinterpret_cast<half4*>(xbuf + frow * 64 + ((g ^ ll_swz(frow)) << 4) + 8 * fhalf) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the buffer is wave-private, no barrier needed
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = h * 16 + (lane >> 2), c = lane & 3;
+          const half8 o = *reinterpret_cast<const half8*>(xbuf + r * 64 + ((c ^ ll_swz(r)) << 4));
+          const int m = m0 + j * 32 + r;
+          if (m < p.M) *reinterpret_cast<half8*>(p.Y + (size_t)m * p.N + nl + c * 8) = o;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // the reads are done before the next tile overwrites the buffer
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  };
+
+  // ---- column block 0: the first loop of k_rows512
+  zero_acc();
+#pragma unroll
+  for (int j = 0; j < LL_LA - LL_LW; ++j) request_a(j);
+#pragma unroll
+  for (int j = 0; j < LL_LW; ++j) { request_a(j + LL_LA - LL_LW); request_w(p.Wp, j, j); }
+  ll_wait_vm(ll_after_w(0));
+  __builtin_amdgcn_s_barrier();
+  read_a(0, 0, 0);
+#pragma unroll
+  for (int ks = 0; ks < LL_NK; ++ks) {
+    if (ks + LL_LA < LL_NK) request_a(ks + LL_LA);
+    if (ks + LL_LW < LL_NK) request_w(p.Wp, ks + LL_LW, (ks + LL_LW) % (LL_LW + 1));
+    read_a(ks, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(ks % (LL_LW + 1), 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < LL_NK) {
+      ll_wait_vm(ll_after_w(ks + 1));
+      __builtin_amdgcn_s_barrier();
+      read_a(ks + 1, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(ks % (LL_LW + 1), 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- the other column blocks: the A tile is complete and visible (the last barrier above came after every block had landed)
+  if (nblk > 1) {
+#pragma unroll
+    for (int j = 0; j < LL_LW; ++j) request_w(p.Wp + (size_t)LL_BN * LL_K, j, j);   // the next block's first weight fragments travel under the stores
+  }
+  store_block(0);
+#pragma unroll 1
+  for (int nb = 1; nb < nblk; ++nb) {
+    const _Float16* wp = p.Wp + (size_t)nb * LL_BN * LL_K;
+    zero_acc();
+    read_a(0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < LL_NK; ++ks) {
+      if (ks + LL_LW < LL_NK) request_w(wp, ks + LL_LW, (ks + LL_LW) % (LL_LW + 1));
+      read_a(ks, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(ks % (LL_LW + 1), 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < LL_NK) read_a(ks + 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(ks % (LL_LW + 1), 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nb + 1 < nblk) {
+#pragma unroll
+      for (int j = 0; j < LL_LW; ++j) request_w(wp + (size_t)LL_BN * LL_K, j, j);
+    }
+    store_block(nb);
+  }
+}
+
 // out[g][c] = mean over the rows of group g of LN(...) * gamma + beta from the chunk sums (16 rows each), chunks in increasing order
 __global__ __launch_bounds__(512) void k_ln_mean_finish(const float* __restrict__ part, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ out, int S) {
@@ -435,6 +614,27 @@ extern "C" int fp_pack_linear512_f16(const void* w16, void* packed, void* stream
   hipLaunchKernelGGL(k_pack_w512, dim3(LL_BN * LL_K / 8 / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w16, (_Float16*)packed,
                      LL_K);
   FP_CHECK_LAUNCH("fp_pack_linear512_f16");
+  return FP_OK;
+}
+
+// y16 (M, N) = f16(x16 (M, 512) @ W^T + bias) [+ ReLU] for N = 512 n <= 2048: nn.Linear under autocast (fp32 accumulation + bias,
+// one rounding), the in_proj of nn.MultiheadAttention (N = 1536; refine_network.py:56-70, score_network.py:52-53).  The bits of
+// fp_igemm_f16_fwd (taps = 1): the same k order per accumulator.  w_packed: N / 512 blocks of 512 output channels, each
+// fp_pack_linear512_f16'ed, back to back.  include/fp_amd.h.
+extern "C" int fp_linear512_f16_fwd(const void* x16, const void* w_packed, const float* bias, void* y16, int M, int N, int relu,
+                                    void* stream) {
+  FP_REQUIRE(M >= 0, "fp_linear512_f16_fwd: M < 0");
+  if (M == 0) return FP_OK;
+  FP_REQUIRE(x16 && w_packed && y16, "fp_linear512_f16_fwd: NULL tensor");
+  FP_REQUIRE(N >= LL_BN && N % LL_BN == 0 && N <= L5_MAX_N, "fp_linear512_f16_fwd: N=%d must be a multiple of 512, at most %d", N, L5_MAX_N);
+  FP_REQUIRE((long long)M * N < (1ll << 31), "fp_linear512_f16_fwd: output exceeds 2^31 elements");
+  FP_REQUIRE((((size_t)x16 | (size_t)w_packed | (size_t)bias | (size_t)y16) & 15) == 0, "fp_linear512_f16_fwd: tensors must be 16-byte aligned");
+  Linear512Params p;
+  p.X = (const _Float16*)x16; p.Wp = (const _Float16*)w_packed; p.bias = bias; p.Y = (_Float16*)y16; p.M = M; p.N = N; p.relu = relu ? 1 : 0;
+  const int lds = l5_lds(N);
+  FP_SET_MAX_LDS(k_linear512, l5_lds(L5_MAX_N));
+  hipLaunchKernelGGL(k_linear512, dim3(fp_cdiv(M, LL_BM)), dim3(LL_THREADS), lds, (hipStream_t)stream, p);
+  FP_CHECK_LAUNCH("fp_linear512_f16_fwd");
   return FP_OK;
 }
 

@@ -63,6 +63,14 @@ FUSED_OUT_PROJ_LN = os.environ.get("FP_AMD_FUSED_LN", "1") != "0"
 FUSED_FFN = os.environ.get("FP_AMD_FUSED_FFN", "1") != "0"
 
 
+# The in_proj of the self-attention blocks (512 -> 1536) on the row-owning tile (csrc/linear_ln.hip, fp_linear512_f16_fwd): the 128 x 512
+# input tile of a workgroup is fetched once for the three column blocks, weights come fragment-packed from L2 into registers.  The bits
+# of fp_igemm_f16_fwd (tests/test_gpu_parity.py::test_linear512_is_the_igemm_linear).  FP_AMD_ROWS_QKV=0 goes back to fp_igemm_f16_fwd;
+# launches below ROWS_QKV_MIN_ROWS rows (the scorer's cross-hypothesis attention: 252 rows) stay there as well.
+ROWS_QKV = os.environ.get("FP_AMD_ROWS_QKV", "1") != "0"
+ROWS_QKV_MIN_ROWS = 4096
+
+
 def _conv_backend():
     if USE_MIOPEN or not torch.backends.cudnn.is_available():
         return contextlib.nullcontext()
@@ -305,11 +313,16 @@ class _HipMHA:
         self.out = _HipLinear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
         self.out_rows = _HipRowsLinear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
         self.nhead, self.fp16_scores = nhead, fp16_scores
+        self.qkv_p = ops.PackedLinear512(self.qkv.w) if tuple(self.qkv.w.shape) == (1536, 512) else None
 
     def context(self, x16):
         """softmax(q k^T / sqrt(d)) v with heads merged, before the output projection: (Bn, L, D) fp16"""
         Bn, L, D = x16.shape
-        return ops.attention_f16(self.qkv(x16).reshape(Bn, L, 3 * D), self.nhead, fp16_scores=self.fp16_scores)
+        if ROWS_QKV and self.qkv_p is not None and Bn * L >= ROWS_QKV_MIN_ROWS:
+            qkv = ops.linear512(x16, self.qkv_p, self.qkv.b)
+        else:
+            qkv = self.qkv(x16)
+        return ops.attention_f16(qkv.reshape(Bn, L, 3 * D), self.nhead, fp16_scores=self.fp16_scores)
 
     def __call__(self, x16):
         return self.out(self.context(x16))

@@ -368,21 +368,43 @@ def layernorm_res(branch16, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None
 
 
 class PackedLinear512:
-    """fragment-packed copy of a (512, 512) fp16 nn.Linear weight (fp_pack_linear512_f16): what linear_layernorm_res and
-    ffn_layernorm_mean take, whose waves read their weight rows straight from L2 into MFMA operand registers"""
+    """fragment-packed copy of a (512 n, 512) fp16 nn.Linear weight (fp_pack_linear512_f16 per block of 512 output channels): what
+    linear512, linear_layernorm_res and ffn_layernorm_mean take, whose waves read their weight rows straight from L2 into MFMA
+    operand registers"""
 
     def __init__(self, w16):
         w = _dev(w16, torch.float16, "w16")
-        if tuple(w.shape) != (512, 512):
-            raise _lib.FpAmdError(f"PackedLinear512: weight {tuple(w.shape)}, must be (512, 512)")
+        if w.dim() != 2 or int(w.shape[1]) != 512 or int(w.shape[0]) % 512 or int(w.shape[0]) == 0:
+            raise _lib.FpAmdError(f"PackedLinear512: weight {tuple(w.shape)}, must be (512 n, 512)")
+        self.out_features = int(w.shape[0])
         self.data = torch.empty_like(w)
-        _lib.check(_lib.lib().fp_pack_linear512_f16(_ptr(w), _ptr(self.data), _stream(w)), "fp_pack_linear512_f16")
+        for blk in range(self.out_features // 512):
+            _lib.check(_lib.lib().fp_pack_linear512_f16(_ptr(w[blk * 512:]), _ptr(self.data[blk * 512:]), _stream(w)), "fp_pack_linear512_f16")
 
 
-def _packed(w, name):
+def _packed(w, name, out_features=512):
     if not isinstance(w, PackedLinear512):
         raise _lib.FpAmdError(f"{name}: the weight must be a PackedLinear512 (ops.PackedLinear512(w16))")
+    if out_features is not None and w.out_features != out_features:
+        raise _lib.FpAmdError(f"{name}: packed weight has {w.out_features} output features, expected {out_features}")
     return w.data
+
+
+def linear512(x16, w_packed, bias, relu=False, out=None):
+    """f16(x16 @ W^T + bias) for x16 (..., 512) fp16 and a PackedLinear512 of W (512 n, 512), n <= 4 (fp_linear512_f16_fwd): the
+    input tile of a workgroup is fetched once for all n column blocks; the bits of igemm_f16 with taps = 1"""
+    x = _dev(x16, torch.float16, "x16")
+    w = _packed(w_packed, "linear512", None)
+    if int(x.shape[-1]) != 512:
+        raise _lib.FpAmdError(f"linear512: x16 (..., {int(x.shape[-1])}), must be (..., 512)")
+    N = w_packed.out_features
+    M = x.numel() // 512
+    y = out if out is not None else torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float16, device=x.device)
+    if y.dtype != torch.float16 or y.numel() != M * N or not y.is_contiguous():
+        raise _lib.FpAmdError("linear512: out must be a contiguous fp16 tensor of M x N elements")
+    _lib.check(_lib.lib().fp_linear512_f16_fwd(_ptr(x), _ptr(w), _ptr(_dev(bias, torch.float32, "bias")), _ptr(y), M, N, 1 if relu else 0,
+                                               _stream(x)), "fp_linear512_f16_fwd")
+    return y
 
 
 def linear_layernorm_res(x16, w_packed, bias, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None, want32=True, want16=True):
@@ -596,6 +618,9 @@ replicate_channels = _timed("fp_replicate_rows_f16", replicate_channels,
 layernorm_res = _timed("fp_layernorm_res_fwd", layernorm_res,
                        lambda br, *a, **k: ((2.0 + (4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)
                                              + (2.0 if k.get("want16", True) else 0.0)) * br.numel(), 0.0))
+linear512 = _timed("fp_linear512_f16_fwd", linear512,
+                   lambda x, w, *a, **k: (2.0 * x.numel() + 2.0 * 512 * w.out_features + 2.0 * (x.numel() // 512) * w.out_features,
+                                          2.0 * x.numel() * w.out_features))
 linear_layernorm_res = _timed("fp_linear_layernorm_fwd", linear_layernorm_res,
                               lambda x, w, *a, **k: (2.0 * x.numel() + 2.0 * 512 * 512 + (x.numel() // x.shape[-1]) * 512 *
                                                      ((4.0 if k.get("x32") is not None else 2.0) + (4.0 if k.get("want32", True) else 0.0)

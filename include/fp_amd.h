@@ -200,6 +200,15 @@ int fp_layernorm_res_fwd(const float* x32 /*dev|NULL*/, const void* tok16 /*dev|
  * cache).  Same size as the matrix; done once per weight matrix; `packed` must not alias `w16`. */
 int fp_pack_linear512_f16(const void* w16 /*dev*/, void* packed /*dev*/, void* stream);
 
+/* y16 (M, N) = f16(x16 (M, 512) @ W^T + bias) [ReLU if relu != 0]: nn.Linear under autocast (fp16 operands, fp32 accumulation +
+ * bias, one rounding) for in_features = 512 and N = 512 n <= 2048 output features -- the in_proj of nn.MultiheadAttention (N = 1536;
+ * refine_network.py:56-70 through nn.TransformerEncoderLayer, score_network.py:52-53,73,86).  The bits of fp_igemm_f16_fwd with
+ * taps = 1 (same k order per accumulator); a workgroup fetches its 128 x 512 input tile once and keeps it in LDS for all N / 512
+ * column blocks, weights from L2 into registers.  w_packed: the N / 512 blocks of 512 output channels of W (N, 512), each through
+ * fp_pack_linear512_f16, back to back; bias (N) f32 | NULL. */
+int fp_linear512_f16_fwd(const void* x16 /*dev*/, const void* w_packed /*dev*/, const float* bias /*dev|NULL*/, void* y16 /*dev*/,
+                         int M, int N, int relu, void* stream);
+
 /* A 512 -> 512 nn.Linear of the encoder layer (refine_network.py:56-70: self_attn.out_proj or linear2, under autocast: fp16
  * operands, fp32 accumulation + bias, one rounding to fp16) fused with the residual add and the LayerNorm that consume it:
  * fp_igemm_f16_fwd (taps = 1, N = 512) followed by fp_layernorm_res_fwd with branch16 = that product, in one launch and

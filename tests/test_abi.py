@@ -63,6 +63,9 @@ def test_argument_errors_are_reported_without_gpu():
     assert b"K=256" in lib.fp_last_error()
     assert lib.fp_pack_linear512_f16(C.c_void_p(16), C.c_void_p(16), None) == -1                                   # in place
     assert lib.fp_pack_linear512_f16(None, C.c_void_p(16), None) == -1
+    assert lib.fp_linear512_f16_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), 4, 768, 0, None) == -1        # N % 512
+    assert b"multiple of 512" in lib.fp_last_error()
+    assert lib.fp_linear512_f16_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), 0, 1536, 0, None) == 0        # nothing to do
     assert lib.fp_linear_layernorm_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400,
                                        C.c_void_p(16), C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 512, 512, None) == -1   # residual twice
     assert lib.fp_replicate_rows_f16(C.c_void_p(16), C.c_void_p(32), 3, 10, 100, 256, 256, 2560, None) == -1      # 100 channels

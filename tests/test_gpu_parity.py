@@ -641,6 +641,30 @@ def test_linear_layernorm_is_the_two_kernel_path(dev):
             assert only16[0] is None and torch.equal(only16[1], want16)
 
 
+def test_linear512_is_the_igemm_linear(dev):
+    """fp_linear512_f16_fwd (the in_proj of the attention blocks on the row-owning tile: input tile fetched once for all column
+    blocks, weights fragment-packed from L2) returns the bits of fp_igemm_f16_fwd: N = 512 / 1536 / 2048, full, ragged and tiny row
+    counts, with and without ReLU and bias; nothing outside the output is written"""
+    from foundationpose_amd import ops
+    from foundationpose_amd.engine import _HipLinear
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for N in (1536, 512, 2048):
+        lin = _HipLinear((torch.randn((N, 512), generator=g) * 0.05).to(dev), (torch.randn((N,), generator=g) * 0.1).to(dev))
+        wp = ops.PackedLinear512(lin.w)
+        for M in (126 * 400, 3 * 400, 129, 1):
+            x = torch.randn((M, 512), generator=g).to(torch.float16).to(dev)
+            for relu in (False, True):
+                want = lin(x, relu=relu)
+                arena = torch.full((M * N + 2048,), -7.0, dtype=torch.float16, device=dev)
+                got = ops.linear512(x, wp, lin.b, relu=relu, out=arena[1024:1024 + M * N].view(M, N))
+                assert torch.equal(got, want), (N, M, relu)
+                assert bool((arena[:1024] == -7).all()) and bool((arena[1024 + M * N:] == -7).all()), (N, M)
+        nob = ops.linear512(x, wp, None)
+        assert torch.equal(nob, _HipLinear(lin.w, torch.zeros(N, device=dev))(x))
+    with pytest.raises(Exception):
+        ops.linear512(torch.zeros((4, 256), dtype=torch.float16, device=dev), wp, None)
+
+
 def test_ffn_layernorm_mean_is_the_three_kernel_path_up_to_summation_order(dev):
     """fp_ffn_layernorm_mean_fwd (linear1 + ReLU + linear2 + residual + norm2 + token mean in one launch) against 2 x fp_igemm_f16_fwd +
     fp_colmean_f16_fwd: the same rounding points, the token mean summed in another fixed fp32 order -> equal to ~1e-6 of the values; and
