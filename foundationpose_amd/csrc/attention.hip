@@ -25,6 +25,20 @@
 #include <type_traits>
 #include "fp_common.h"
 
+#ifdef FP_PROFILE_BUILD
+// profiling build only: 100 MHz wall-clock time per phase of k_attention_f16 (thread 0 of every workgroup), summed over the workgroups of
+// a launch (scripts/dbg_attention.py): [0] prologue (Q fragments, K(0), V(0) resident), [1] the block loop, [2] output, [3] workgroups,
+// [6] / [7] first start / last end
+__device__ unsigned long long at_dbg[8];
+extern "C" int fp_dbg_attention(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, ~0ull, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(at_dbg), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(at_dbg), 8 * sizeof(unsigned long long));
+}
+#define AT_CLK(t) const unsigned long long t = wall_clock64()
+#else
+#define AT_CLK(t)
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -82,6 +96,7 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
   const int q0 = (qg * WAVES + wid) * (32 * QT);   // first query row of this wave
   const bool wave_active = q0 < S;                 // idle waves still help staging and keep the barriers matched
 
+  AT_CLK(t_start);
   // ---- Q fragments (B operand): row q0 + 32 t + lq, d = 16 kk + 8 hi + 0..7
   half8 qf[QT][8];
 #pragma unroll
@@ -174,6 +189,7 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
   vstore(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  AT_CLK(t_pro);
   auto do_block = [&](int blk, auto half_c) {
     const int cur = blk & 1;
     if (blk + 1 < nblk) stage_next(blk + 1, cur ^ 1);   // in flight while this block is multiplied
@@ -322,6 +338,7 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
   if ((nblk - 1) * AT_KB + 32 >= S) do_block(nblk - 1, std::true_type{});
   else do_block(nblk - 1, std::false_type{});
 
+  AT_CLK(t_loop);
   // ---- normalise, transpose through a wave-private LDS tile [32 QT queries][128 d] (16-byte chunks XORed with q & 15),
   // store whole 256-byte rows
   unsigned char* tile = smem + wid * (32 * QT * 256);   // WAVES x 8 QT KiB = 64 KiB inside the two buffers (everyone is past the last barrier)
@@ -353,6 +370,14 @@ __global__ __launch_bounds__(WAVES * 64, QT == 1 ? 2 : 1) void k_attention_f16(c
       }
     }
   }
+#ifdef FP_PROFILE_BUILD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AT_CLK(t_end);
+  if (tid == 0) {
+    atomicAdd(&at_dbg[0], t_pro - t_start); atomicAdd(&at_dbg[1], t_loop - t_pro); atomicAdd(&at_dbg[2], t_end - t_loop);
+    atomicAdd(&at_dbg[3], 1ull); atomicMin(&at_dbg[6], t_start); atomicMax(&at_dbg[7], t_end);
+  }
+#endif
 }
 
 template <int QT, int WAVES>
