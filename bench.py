@@ -528,7 +528,16 @@ def main():
             _log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()
         faulthandler.cancel_dump_traceback_later()
-        print(json.dumps(out))
+        if use_dist:
+            dist.barrier()                  # the other ranks are done talking
+        try:                                # RCCL announces itself through C stdio ("Librccl path : ..."), which a pipe buffers
+            import ctypes                   # until exit: empty that buffer first, so that the JSON line is the last line
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+    elif use_dist:
+        dist.barrier()
     if use_dist:
         dist.destroy_process_group()
 
