@@ -230,6 +230,17 @@ class ClockSampler:
         return out
 
 
+def _flush_c_stdio():
+    """RCCL announces itself through C stdio ("Librccl path : ..."), which a pipe buffers until exit: every rank empties that
+    buffer before the final barrier, so that rank 0's JSON line is the last line of the job's stdout"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,15 +539,12 @@ def main():
             _log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()
         faulthandler.cancel_dump_traceback_later()
+        _flush_c_stdio()
         if use_dist:
-            dist.barrier()                  # the other ranks are done talking
-        try:                                # RCCL announces itself through C stdio ("Librccl path : ..."), which a pipe buffers
-            import ctypes                   # until exit: empty that buffer first, so that the JSON line is the last line
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
+            dist.barrier()                  # the other ranks have emptied theirs
         print(json.dumps(out), flush=True)
     elif use_dist:
+        _flush_c_stdio()
         dist.barrier()
     if use_dist:
         dist.destroy_process_group()
