@@ -63,8 +63,8 @@ __device__ __forceinline__ int sw_q(const IgemmGeom& g, int m) {
   return (b * g.Hp + oy) * g.Wp + ox;
 }
 
-// Tile shapes: 256 x 256 (N % 256 == 0: each wave 128 x 64 outputs), 512 x 128 (N = 128: the same 128 x 64 per wave, so the
-// 128-channel stem layers run 16 MFMAs per wave and k-step like the wide layers instead of 8 behind the same barriers).
+// Tile shapes: 512 x 128 (the product's, every layer since round 4: see SW_FORCE_512 below) and 256 x 256 (N % 256 == 0); each wave owns
+// 128 x 64 outputs = 16 MFMAs per k-step either way.
 template <int BM, int BN, int TM>
 __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
   constexpr int BK = SW_BK, NW = 8, THREADS = 512;
@@ -493,7 +493,14 @@ static int sw_variant(const IgemmParams& p) {
   return v;
 }
 
-static int sw_tile_rows(const IgemmParams& p) { return sw_variant(p) == 1 ? 256 : ((p.N % 256) == 0 ? 256 : 512); }
+// Round 4: 512 x 128 tiles for EVERY layer, also where N is a multiple of 256 (-DSW_FORCE_512=0 restores 256 x 256 there).  Per k-step a
+// 256 x 256 tile stages 16 KB of weights + ~3.5 KB of patch for its 128 MFMAs, a 512 x 128 tile 8 KB + ~5 KB: a third fewer LDS-DMA
+// pieces per MFMA, and the pieces' issue cost next to MFMAs is what the main loop is bound by; the activation rows are
+// then fetched once per column tile (from L2 the second time).  Same k order per accumulator: the same bits.
+#ifndef SW_FORCE_512
+#define SW_FORCE_512 1
+#endif
+static int sw_tile_rows(const IgemmParams& p) { return sw_variant(p) == 1 ? 256 : (((p.N % 256) == 0 && !SW_FORCE_512) ? 256 : 512); }
 
 bool fp_conv3x3_sw_applicable(const IgemmParams& p) {
   const IgemmGeom& g = p.in;
@@ -511,6 +518,6 @@ int fp_conv3x3_sw_tile_rows(const IgemmParams& p) { return sw_tile_rows(p); }
 
 int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream) {
   if (sw_variant(p) == 1) return sw_ls_launch<256, 128, 4>(p, stream);
-  if ((p.N % 256) == 0) return sw_launch<256, 256, 4>(p, stream);
+  if ((p.N % 256) == 0 && !SW_FORCE_512) return sw_launch<256, 256, 4>(p, stream);
   return sw_launch<512, 128, 4>(p, stream);
 }
