@@ -21,3 +21,45 @@ def test_resolve_shared_translation():
     R[2, 0, 3] += 1e-12                                                     # equal as the float32 values that are uploaded
     assert rs(R, None) is True
     assert rs(np.zeros((0, 4, 4)), None) is False
+
+
+def test_graph_cache_auto_captures_on_the_second_sighting_and_evicts_lru():
+    """graphs.GraphCache (what `graph="auto"` of the predictors means): pure bookkeeping, no GPU"""
+    from foundationpose_amd.graphs import GraphCache
+    built = []
+
+    def build(tag):
+        def b():
+            built.append(tag)
+            return ("graph", tag)
+        return b
+    c = GraphCache(cap=2)
+    assert c.get("a", False, build("a")) is None and c.get("a", False, build("a")) is None and built == []     # never
+    assert c.get("b", "auto", build("b")) is None and built == []                                              # first sighting: eager
+    assert c.get("b", "auto", build("b")) == ("graph", "b") and built == ["b"]                                 # second: captured
+    assert c.get("b", "auto", build("b")) == ("graph", "b") and built == ["b"]                                 # then replayed
+    assert c.get("c", True, build("c")) == ("graph", "c") and built == ["b", "c"]                              # True: at once
+    assert c.get("b", False, build("b")) == ("graph", "b")          # a captured key is served whatever the mode; b is now the most recent
+    assert c.get("d", True, build("d")) == ("graph", "d")           # cap 2: the least recently used (c) goes
+    assert set(c.items) == {"b", "d"}
+    assert c.get("c", "auto", build("c")) == ("graph", "c")         # c had been seen before: its second 'auto' sighting captures again
+    assert set(c.items) == {"d", "c"} and built == ["b", "c", "d", "c"]
+    for k in range(70):                                             # the sighting counters are bounded
+        c.get(("k", k), "auto", build(k))
+    assert len(c.seen) <= 64
+
+
+def test_fragment_packed_weight_layout_is_what_the_mfma_operand_needs():
+    """the layout fp_pack_linear512_f16 documents (include/fp_amd.h), restated in numpy: for channel group w, k16-step q, channel tile i
+    the 64 lanes' operands stand back to back, lane l holding W[64 w + 32 i + (l & 31)][16 q + 8 (l >> 5) .. + 8].  The GPU test
+    compares the kernel's output with the same permutation; here: it is a permutation (nothing lost, nothing doubled) and one wave
+    load -- 64 lanes x 8 halves -- is one contiguous KiB holding exactly the 32 rows x 16 columns an MFMA operand covers."""
+    W = np.arange(512 * 512, dtype=np.int64).reshape(512, 512)
+    packed = W.reshape(8, 2, 32, 32, 2, 8).transpose(0, 3, 1, 4, 2, 5).reshape(-1)       # [w, q, i, l >> 5, l & 31, 8]
+    assert np.array_equal(np.sort(packed), np.arange(512 * 512))
+    for (w, q, i) in ((0, 0, 0), (3, 17, 1), (7, 31, 1)):
+        blk = packed[(((w * 32 + q) * 2 + i) * 64) * 8:][:512]                           # one wave load = 512 halves = 1 KiB
+        rows, cols = np.unique(blk // 512), np.unique(blk % 512)
+        assert np.array_equal(rows, 64 * w + 32 * i + np.arange(32)) and np.array_equal(cols, 16 * q + np.arange(16))
+        lane = 37                                                                        # lane 37 = row 5, upper k half
+        assert np.array_equal(blk[lane * 8:lane * 8 + 8], W[64 * w + 32 * i + 5, 16 * q + 8:16 * q + 16])
