@@ -500,7 +500,10 @@ static int sw_variant(const IgemmParams& p) {
 #ifndef SW_FORCE_512
 #define SW_FORCE_512 1
 #endif
-static int sw_tile_rows(const IgemmParams& p) { return sw_variant(p) == 1 ? 256 : (((p.N % 256) == 0 && !SW_FORCE_512) ? 256 : 512); }
+// (launches of fewer than two 512-row tiles keep the 256 x 256 shape where it exists, so that the smallest batches -- two hypotheses on
+// the 20 x 20 layers -- stay on this kernel and on its summation order, as before the change)
+static bool sw_use_256(const IgemmParams& p) { return (p.N % 256) == 0 && (!SW_FORCE_512 || p.M < 2 * 512); }
+static int sw_tile_rows(const IgemmParams& p) { return sw_variant(p) == 1 ? 256 : (sw_use_256(p) ? 256 : 512); }
 
 bool fp_conv3x3_sw_applicable(const IgemmParams& p) {
   const IgemmGeom& g = p.in;
@@ -518,6 +521,6 @@ int fp_conv3x3_sw_tile_rows(const IgemmParams& p) { return sw_tile_rows(p); }
 
 int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream) {
   if (sw_variant(p) == 1) return sw_ls_launch<256, 128, 4>(p, stream);
-  if ((p.N % 256) == 0 && !SW_FORCE_512) return sw_launch<256, 256, 4>(p, stream);
+  if (sw_use_256(p)) return sw_launch<256, 256, 4>(p, stream);
   return sw_launch<512, 128, 4>(p, stream);
 }
