@@ -55,27 +55,65 @@ class GraphCache:
     """what `graph="auto"` of the predictors means: a (shape, intrinsics, mesh, ...) key is captured the SECOND time it is
     seen -- a single call (a test, one register()) stays eager, a loop over frames or objects of one shape replays graphs from
     its third pass on -- and at most `cap` captured keys are kept (least recently used first out; a capture owns a private
-    memory pool)."""
+    memory pool).
 
-    def __init__(self, cap=4):
+    Guard rails (round 5, the advisor's finding): a capture costs two eager warm-ups, a device synchronisation, the captures and a
+    private pool -- about four eager calls, for a replay that saves a few per cent of one -- so a key set larger than `cap` visited
+    round-robin (five tracked objects; register and track keys mixed) must not turn into capture-evict-capture.  (i) Under 'auto' a
+    full cache evicts only an entry that has not been replayed for `stale_after` calls of get(); otherwise the new key runs eagerly
+    and the resident captures keep replaying.  (`True` is an explicit request and evicts the least recently used entry at once.)
+    (ii) An evicted key forgets its sightings: it needs two fresh ones before it is captured again.  (iii) Under 'auto' a failing
+    build() (out of memory in a private pool, a capture error) is logged once per key, the key is left eager for good, and the call
+    runs eagerly; `True` still raises."""
+
+    def __init__(self, cap=4, stale_after=64):
         self.cap, self.seen, self.items = cap, {}, {}
+        self.stale_after, self.clock, self.last_use, self.failed = stale_after, 0, {}, set()
+        self.stats = dict(captures=0, replays=0, evictions=0, eager_by_guard=0, build_failures=0)
 
     def get(self, key, mode, build):
         """mode True: capture now; 'auto': on the second sighting; -> the captured object or None (= run eagerly)"""
+        self.clock += 1
         it = self.items.pop(key, None)
         if it is not None:
             self.items[key] = it          # most recently used last
+            self.last_use[key] = self.clock
+            self.stats["replays"] += 1
             return it
+        if mode is False or mode is None:
+            return None
         n = self.seen[key] = self.seen.get(key, 0) + 1
         if len(self.seen) > 64:
             self.seen = {key: n}
-        if mode is True or (mode == "auto" and n >= 2):
+        if mode == "auto":
+            if n < 2 or key in self.failed:
+                return None
+            if len(self.items) >= self.cap and self.clock - self.last_use[next(iter(self.items))] <= self.stale_after:
+                self.stats["eager_by_guard"] += 1      # (i): the residents are in use; this key stays eager
+                return None
+        try:
             it = build()
-            self.items[key] = it
-            while len(self.items) > self.cap:
-                self.items.pop(next(iter(self.items)))
-            return it
-        return None
+        except Exception as e:           # noqa: BLE001 -- whatever the capture raised, 'auto' must not take the call down
+            if mode is True:
+                raise
+            import logging
+            logging.getLogger(__name__).warning("graph capture failed for %r (%s: %s); this key stays on eager launches",
+                                                key, type(e).__name__, e)
+            self.failed.add(key)
+            if len(self.failed) > 64:
+                self.failed = {key}
+            self.stats["build_failures"] += 1
+            return None
+        self.stats["captures"] += 1
+        self.items[key] = it
+        self.last_use[key] = self.clock
+        while len(self.items) > self.cap:
+            old = next(iter(self.items))
+            self.items.pop(old)
+            self.last_use.pop(old, None)
+            self.seen.pop(old, None)      # (ii): two fresh sightings before it is captured again
+            self.stats["evictions"] += 1
+        return it
 
 
 class GraphedTracker:

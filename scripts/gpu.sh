@@ -1,0 +1,88 @@
+#!/bin/bash
+# ONE parameterised GPU-box script (replaces the fifty single-use scripts/gpu_r*_*.sh of rounds 2-4):
+#   gpurun --timeout 1500 -- 'TAG=r05_a bash scripts/gpu.sh sane tests bench prof pmc track smoke'
+# Every task writes gpurun_out/${TAG}_<task>.*; summaries worth keeping are copied into profiles/ by hand afterwards.
+export TMPDIR=/tmp
+TAG=${TAG:-r05}
+O=gpurun_out
+mkdir -p $O
+T0=$(date +%s)
+el() { echo "== $1 (t=$(( $(date +%s) - T0 )) s)"; }
+CS=foundationpose_amd/csrc
+BENCH_FAST="--no-cpu-baseline --no-kernel-table"
+
+t_sane() {
+  timeout 200 python -c "import torch; x = torch.ones(1 << 22, device='cuda'); assert (x * 2).sum().item() == 2 * (1 << 22); print('gpu sane')" || { echo "GPU NOT SANE"; exit 7; }
+}
+t_tests() {   # the whole GPU suite
+  timeout 1500 python -m pytest tests/ -m gpu -q --timeout 900 --durations=8 > $O/${TAG}_pytest_gpu.log 2>&1; tail -16 $O/${TAG}_pytest_gpu.log | cut -c1-300
+}
+t_tests_fast() {   # everything but the three long parity chains
+  timeout 900 python -m pytest tests/ -m gpu -q --timeout 600 -x -k "not teacher_forced and not fp32_matches_oracle and not scorer_252_vs_exact" > $O/${TAG}_pytest_gpu_fast.log 2>&1; tail -8 $O/${TAG}_pytest_gpu_fast.log | cut -c1-300
+}
+t_bench() {   # the driver's command
+  timeout 400 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; python scripts/show_bench_kernels.py $O/${TAG}_bench.json
+}
+bench_line() {  # name, env/lib, extra flags: one short line per variant (A/B runs on the same box)
+  local name=$1 lib=$2; shift 2
+  FP_AMD_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 5 $BENCH_FAST "$@" > $O/${TAG}_bench_$name.json 2> $O/${TAG}_bench_$name.err
+  python - $O/${TAG}_bench_$name.json $name <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    c = d.get("clock", {})
+    print(f"   {sys.argv[2]:28s} {d['ms_per_step']:.3f} ms/step  {d['value']:.0f} hyp/s  sclk {c.get('sclk_MHz_mean') or 0:.0f} MHz  {c.get('power_W_mean') or 0:.0f} W")
+except Exception as e:
+    print("   ", sys.argv[2], "FAILED", e)
+PY
+}
+t_ab() {      # same box, back to back: product, lock-step two-per-CU conv (make ab), 3 sub-batch streams; product again
+  bench_line product $PWD/$CS/libfp_amd.so
+  [ -f $CS/libfp_amd_alt.so ] && bench_line conv_sw_ls $PWD/$CS/libfp_amd_alt.so
+  bench_line streams3 $PWD/$CS/libfp_amd.so --streams 3
+  bench_line product_again $PWD/$CS/libfp_amd.so
+}
+t_probe() {   # MFMA / VALU co-issue probe (scripts/mfma_valu_overlap)
+  hipcc --offload-arch=gfx950 -O3 -pthread -o /tmp/mvprobe scripts/mfma_valu_overlap/probe.hip && timeout 300 /tmp/mvprobe > $O/${TAG}_mfma_valu_probe.log 2>&1; cat $O/${TAG}_mfma_valu_probe.log
+}
+t_conv_phases() {
+  FP_AMD_LIB=$PWD/$CS/libfp_amd_profile.so timeout 300 python scripts/dbg_conv_sw_step.py 2> /dev/null | tee $O/${TAG}_conv_sw_step_phases.log
+  FP_AMD_LIB=$PWD/$CS/libfp_amd_profile.so timeout 300 python scripts/dbg_conv_sw.py 2> /dev/null | tee $O/${TAG}_conv_sw_phases.log
+}
+t_prof() {    # bench --serialize under rocprofv3 --stats
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o bench -- python bench.py --serialize --no-graph --steps 5 --warmup 2 $BENCH_FAST > $O/${TAG}_bench_serialize.json 2> /dev/null
+  python - $O $TAG <<'PY'
+import csv, glob, sys
+O, TAG = sys.argv[1:3]
+f = glob.glob(f"{O}/{TAG}_prof/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+w = csv.DictWriter(open(f"{O}/{TAG}_bench_serialize_kernel_stats.csv", "w"), fieldnames=list(rows[0].keys()))
+w.writeheader()
+for r in rows[:40]:
+    r["Name"] = r["Name"][:90]
+    w.writerow(r)
+for r in rows[:12]:
+    print("  ", r["Name"][:60], r["Calls"], r["AverageNs"], r["Percentage"])
+PY
+  rm -rf $O/${TAG}_prof
+}
+t_pmc() {     # PMC passes over one serialized step (separate passes: FETCH_SIZE, WRITE_SIZE, MFMA busy)
+  local B1="python bench.py --serialize --no-graph --steps 1 --warmup 1 --trace-markers $BENCH_FAST"
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -o k -- $B1 > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -o k -- $B1 > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/${TAG}_pmc_mfma -o k -- $B1 > /dev/null 2>&1
+  local F=$(ls $O/${TAG}_pmc_fetch/*counter_collection.csv | head -1) W=$(ls $O/${TAG}_pmc_write/*counter_collection.csv | head -1) M=$(ls $O/${TAG}_pmc_mfma/*counter_collection.csv | head -1)
+  python scripts/pmc_step_traffic.py "$F" "$W" $O/${TAG}_step_traffic.json > /dev/null; python scripts/pmc_step_mfma.py "$M" $O/${TAG}_step_mfma_busy.json | head -8
+  rm -rf $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_mfma
+}
+t_track() {
+  timeout 400 python scripts/bench_track.py > $O/${TAG}_track_config5.json 2> /dev/null; cut -c1-600 $O/${TAG}_track_config5.json
+}
+t_smoke() {
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | cut -c1-400
+}
+for task in "$@"; do
+  el "$task"
+  if declare -f "t_$task" > /dev/null; then "t_$task"; else echo "unknown task $task"; fi
+done
+el done

@@ -33,7 +33,7 @@ def test_graph_cache_auto_captures_on_the_second_sighting_and_evicts_lru():
             built.append(tag)
             return ("graph", tag)
         return b
-    c = GraphCache(cap=2)
+    c = GraphCache(cap=2, stale_after=0)     # stale_after=0: plain least-recently-used eviction under "auto" as well
     assert c.get("a", False, build("a")) is None and c.get("a", False, build("a")) is None and built == []     # never
     assert c.get("b", "auto", build("b")) is None and built == []                                              # first sighting: eager
     assert c.get("b", "auto", build("b")) == ("graph", "b") and built == ["b"]                                 # second: captured
@@ -42,11 +42,57 @@ def test_graph_cache_auto_captures_on_the_second_sighting_and_evicts_lru():
     assert c.get("b", False, build("b")) == ("graph", "b")          # a captured key is served whatever the mode; b is now the most recent
     assert c.get("d", True, build("d")) == ("graph", "d")           # cap 2: the least recently used (c) goes
     assert set(c.items) == {"b", "d"}
-    assert c.get("c", "auto", build("c")) == ("graph", "c")         # c had been seen before: its second 'auto' sighting captures again
+    assert c.get("c", "auto", build("c")) is None                   # an evicted key forgets its sightings: eager again ...
+    assert c.get("c", "auto", build("c")) == ("graph", "c")         # ... and captured on its second fresh sighting
     assert set(c.items) == {"d", "c"} and built == ["b", "c", "d", "c"]
     for k in range(70):                                             # the sighting counters are bounded
         c.get(("k", k), "auto", build(k))
     assert len(c.seen) <= 64
+
+
+def test_graph_cache_does_not_thrash_and_survives_a_failing_capture():
+    """the advisor's round-4 finding: more live keys than `cap`, visited round-robin (five tracked objects), recaptured an evicted key
+    on its very next sighting -- every call a full capture.  Now: under 'auto' a full cache whose entries are in use is left alone
+    (the surplus keys run eagerly), only stale entries are evicted, and an evicted key needs two fresh sightings."""
+    from foundationpose_amd.graphs import GraphCache
+    built = []
+
+    def build(tag):
+        def b():
+            built.append(tag)
+            return ("graph", tag)
+        return b
+    c = GraphCache(cap=2, stale_after=16)
+    for _ in range(12):                                             # five keys round-robin on a cache of two
+        for k in "abcde":
+            c.get(k, "auto", build(k))
+    # before the fix this loop captured on 55 of its 60 calls; now the cache fills once and its two entries replay ever after
+    assert built == ["a", "b"] and set(c.items) == {"a", "b"}
+    assert c.stats["eager_by_guard"] == 33 and c.stats["replays"] == 20 and c.stats["evictions"] == 0
+    # the residents fall out of use: after `stale_after` calls without a replay the least recently used one makes room
+    for _ in range(12):
+        for k in "cde":
+            c.get(k, "auto", build(k))
+    assert len(c.items) == 2 and not {"a", "b"} & set(c.items) and c.stats["evictions"] == 2
+    assert c.get("a", "auto", build("a")) is None                  # evicted: a fresh first sighting
+    # an explicit request always captures and evicts the least recently used entry
+    lru = next(iter(c.items))
+    assert c.get("z", True, build("z")) == ("graph", "z") and lru not in c.items
+    # a key set that fits is untouched by the guard
+    c2 = GraphCache(cap=4)
+    calls = [c2.get(k, "auto", build(("fit", k))) for _ in range(4) for k in "abc"]
+    assert calls[:3] == [None] * 3 and all(x is not None for x in calls[3:]) and c2.stats["captures"] == 3
+    # a failing build under 'auto': logged, the call runs eagerly, the key is not tried again; True raises
+    c3 = GraphCache()
+    tries = []
+
+    def boom():
+        tries.append(1)
+        raise RuntimeError("HIP out of memory (private pool)")
+    assert c3.get("x", "auto", boom) is None and c3.get("x", "auto", boom) is None and c3.get("x", "auto", boom) is None
+    assert len(tries) == 1 and c3.stats["build_failures"] == 1
+    with pytest.raises(RuntimeError):
+        c3.get("y", True, boom)
 
 
 def test_fragment_packed_weight_layout_is_what_the_mfma_operand_needs():
