@@ -120,6 +120,120 @@ def cpu_baseline(n_hyp=16, iters=5, reps=3):
                        f"raster/warp (OpenMP {oo.num_threads()} thr) + torch-CPU fp32 nets ({torch.get_num_threads()} thr), {dt:.2f} s")
 
 
+def ingest_bench(dev, sc, reps=200):
+    """per-frame ingest (erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch, estimater.py:256-258), the
+    three launches back to back on one stream, HIP events around `reps` frames; input resident in HBM"""
+    from foundationpose_amd import ops
+    d = torch.as_tensor(sc["depth"], device=dev)
+
+    def pre():
+        f = ops.bilateral_filter_depth(ops.erode_depth(d, radius=2), radius=2)
+        return ops.depth_to_xyz(f, sc["K"], zfar=float("inf"), f64_internal=False)
+    for _ in range(5):
+        pre()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        pre()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    H, W = d.shape
+    algo = H * W * 4 * (2 + 2 + 1 + 3)        # read + write per filter, read depth + write xyz
+    return {"us_per_frame": us, "frames_per_sec": 1e6 / us, "algorithmic_bytes": algo, "GBps": algo / us / 1e3,
+            "frac_of_hbm_peak": algo / us / 1e3 / HBM_PEAK_GBS, "frame": [int(H), int(W)],
+            "note": "erode (r=2) + bilateral (r=2) + back-projection, 3 launches, launch-latency bound at this size (1.2 MB frame)"}
+
+
+def make_sequence(dev, sc, frames, seed=7):
+    """config 5's input: `frames` DISTINCT RGB-D frames of the object on a smooth trajectory (<= 4 mm, <= 1.5 deg per frame), each with
+    its own noise / dropout, rendered by the product's rasteriser; pinned host buffers (the H2D copies belong to the timed region)"""
+    from foundationpose_amd import synthetic as syn
+    from foundationpose_amd.Utils import nvdiffrast_render
+    rng = np.random.default_rng(seed)
+    T0 = sc["T"].astype(np.float64)
+    gt = np.zeros((frames, 4, 4))
+    for f in range(frames):
+        a = 2 * np.pi * f / 250.0
+        ax = np.array([np.sin(0.7 * a), np.cos(a), 0.3])
+        ax /= np.linalg.norm(ax)
+        ang = np.deg2rad(20.0) * np.sin(a)
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        dR = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        gt[f] = T0
+        gt[f, :3, :3] = dR @ T0[:3, :3]
+        gt[f, :3, 3] = T0[:3, 3] + np.array([0.06 * np.sin(a), 0.04 * np.sin(2 * a), 0.05 * np.cos(a) - 0.05])
+    rgb_h = torch.empty((frames, syn.H, syn.W, 3), dtype=torch.uint8).pin_memory()
+    depth_h = torch.empty((frames, syn.H, syn.W), dtype=torch.float32).pin_memory()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    bg = torch.as_tensor(np.kron(rng.uniform(0.3, 0.6, size=(syn.H // 8, syn.W // 8, 3)), np.ones((8, 8, 1))), device=dev, dtype=torch.float32)
+    t0 = time.perf_counter()
+    for f in range(frames):
+        color, depth, _ = nvdiffrast_render(K=sc["K"], H=syn.H, W=syn.W, ob_in_cams=torch.as_tensor(gt[f][None], device=dev, dtype=torch.float),
+                                            mesh_tensors=sc["gm"], use_light=True, extra={})
+        mask = depth[0] > 0
+        rgb = torch.where(mask[..., None], color[0], bg)
+        d = torch.where(mask, depth[0], torch.full_like(depth[0], 1.2)) + torch.randn((syn.H, syn.W), generator=gen, device=dev) * 0.001
+        d = torch.where(torch.rand((syn.H, syn.W), generator=gen, device=dev) < 0.02, torch.zeros_like(d), d)
+        rgb_h[f].copy_((rgb.clamp(0, 1) * 255).to(torch.uint8))
+        depth_h[f].copy_(d)
+    torch.cuda.synchronize()
+    return gt, rgb_h, depth_h, time.perf_counter() - t0
+
+
+def tracking_bench(dev, sc, refiner, seq, hyps, iters, latency_frames=200):
+    """BASELINE configs[4] for one (hypotheses per frame, iterations) pair: per frame the uint8 colour image, the
+    float depth map and the hypotheses are uploaded from pinned host memory, then depth erosion + bilateral filter + back-projection +
+    `iters` x (crop windows, rasteriser, observed crop, RefineNet, pose update) run as captured hipGraphs (graphs.GraphedTracker) or
+    as the same launches issued eagerly.  hyps = 1, iters = 2 is the reference's track_one (estimater.py:250-268, run_demo.py:64)."""
+    from foundationpose_amd import synthetic as syn
+    from foundationpose_amd.graphs import GraphedTracker
+    gt, rgb_h, depth_h, t_gen = seq
+    F_ = len(gt)
+    hyp_h = torch.empty((F_, hyps, 4, 4), dtype=torch.float32).pin_memory()
+    for f in range(F_):
+        if hyps == 1:
+            hyp_h[f, 0].copy_(torch.from_numpy(gt[max(f - 1, 0)].astype(np.float32)))      # track_one: the previous frame's pose
+        else:                                                                              # <= 2 cm, <= 10 deg around it
+            hyp_h[f].copy_(torch.from_numpy(syn.perturbed_poses(gt[max(f - 1, 0)], hyps, seed=100 + f, max_trans=0.02, max_rot_deg=10.0).astype(np.float32)))
+    trk = GraphedTracker(refiner, sc["gm"], sc["diameter"], sc["K"], syn.H, syn.W, n_hyp=hyps, iteration=iters, device=dev).capture()
+    rgb_u8 = torch.empty((syn.H, syn.W, 3), dtype=torch.uint8, device=dev)
+
+    def frame(f, graph=True):
+        rgb_u8.copy_(rgb_h[f], non_blocking=True)            # H2D, 0.92 MB
+        trk.rgb.copy_(rgb_u8)                                # u8 -> f32 on the device
+        trk.depth.copy_(depth_h[f], non_blocking=True)       # H2D, 1.2 MB
+        trk.poses_in.copy_(hyp_h[f], non_blocking=True)      # H2D
+        return trk.replay() if graph else trk._body()
+    res, lat = {}, {}
+    with torch.inference_mode():
+        for name, graph in (("hipgraph", True), ("eager", False)):
+            for f in range(5):
+                frame(f, graph)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in range(F_):
+                out = frame(f, graph)
+            torch.cuda.synchronize()
+            res[name] = (time.perf_counter() - t0) / F_
+            # per-frame latency: the host waits for every frame, as a control loop would
+            ls = []
+            for f in range(min(F_, latency_frames)):
+                t0 = time.perf_counter()
+                frame(f, graph)
+                torch.cuda.synchronize()
+                ls.append(time.perf_counter() - t0)
+            lat[name] = {"median": float(np.median(ls) * 1e3), "p95": float(np.percentile(ls, 95) * 1e3)}
+        assert torch.isfinite(out).all()
+    return {"frames": F_, "hypotheses_per_frame": hyps, "refine_iterations": iters, "distinct_frames": F_,
+            "uploads_per_frame_bytes": int(rgb_h[0].numel() + depth_h[0].numel() * 4 + hyp_h[0].numel() * 4),
+            "hipgraph_ms_per_frame": res["hipgraph"] * 1e3, "eager_ms_per_frame": res["eager"] * 1e3,
+            "frames_per_sec": 1.0 / res["hipgraph"], "frames_per_sec_eager": 1.0 / res["eager"],
+            "hypothesis_passes_per_sec": hyps * iters / res["hipgraph"], "speedup_vs_eager": res["eager"] / res["hipgraph"],
+            "latency_ms_synced_per_frame": lat["hipgraph"], "latency_ms_synced_per_frame_eager": lat["eager"]}
+
+
 def _respawn(args):
     """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run"""
     import socket
@@ -264,6 +378,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region instead of hipGraph replays of the "
                     "refine loop and of the scorer's per-hypothesis half (PoseRefinePredictor / ScorePredictor graph=False)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the records next to the headline: per-frame ingest (a1-a3) and tracking "
+                    "mode (BASELINE configs[4] at 64 hypotheses per frame, and the reference's track_one: 1 hypothesis x 2 iterations)")
+    ap.add_argument("--track-frames", type=int, default=1000)
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (instrumented) pass")
     args = ap.parse_args()
 
@@ -535,6 +652,31 @@ def main():
                                         "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,
                                         "frac_of_hbm_peak": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["kernels"] = kern
+            # per-stage rates ("reported separately"): launch time of a stage's entry points per step, one stream, and the
+            # hypothesis-passes/s the stage would sustain alone (a pass = one hypothesis through one refine iteration or the score pass)
+            groups = {"crop_windows": ("fp_crop_windows",), "raster": ("fp_render_crops",), "observed_crop": ("fp_warp_crops",),
+                      "pose_update": ("fp_pose_update",)}
+            net = [n for n in ksum if n not in sum(groups.values(), ())]
+            groups["networks"] = tuple(net)
+            passes = total_hyps // world * (R + 1)
+            stages = {}
+            for g, names in groups.items():
+                ms = sum(ksum[n]["calls"] * ksum[n]["avg_ms"] for n in names if n in ksum) / args.steps
+                if ms > 0:
+                    stages[g] = {"ms_per_step": ms, "hypothesis_passes_per_sec": passes / (ms * 1e-3)}
+            out["stages"] = stages
+        if world == 1 and not args.no_extras and args.precision == "fp16":
+            # outside the headline's timed region, the same process and clock state: SURVEY 8(d) C5 + the per-frame ingest
+            _log("extras: ingest, tracking")
+            out["ingest"] = ingest_bench(dev, sc)
+            trk_ref = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev)
+            seq = make_sequence(dev, sc, args.track_frames)
+            out["tracking"] = {
+                "metric": "tracking frames/sec (BASELINE configs[4]: synthetic RGB-D sequence of distinct frames, per-frame H2D of rgb u8 + "
+                          "depth f32 + hypotheses inside the timed region, depth filters + refine loop as hipGraph replays)",
+                "sequence_generation_s": seq[3],
+                "config5_64hyp_2iter": tracking_bench(dev, sc, trk_ref, seq, 64, 2),
+                "track_one_1hyp_2iter": tracking_bench(dev, sc, trk_ref, seq, 1, 2)}
         if world == 1 and not args.no_cpu_baseline:
             _log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = cpu_baseline()

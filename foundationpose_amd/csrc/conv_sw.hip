@@ -32,6 +32,11 @@ extern "C" int fp_dbg_conv_sw(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, ~0ull, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(sw_dbg), z, sizeof(z)); }
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_dbg), 8 * sizeof(unsigned long long));
 }
+// the epilogue's own phase timers (igemm_epilogue.h, this translation unit's copy): out[0..7]
+extern "C" int fp_dbg_conv_sw_epilogue(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(ig_epi_dbg), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ig_epi_dbg), 8 * sizeof(unsigned long long));
+}
 #define SW_CLK(t) const unsigned long long t = wall_clock64()
 #else
 #define SW_CLK(t)

@@ -6,6 +6,16 @@
 #pragma once
 #include "igemm_common.h"
 
+#ifdef FP_PROFILE_BUILD
+// profiling build only: 100 MHz wall-clock time per epilogue phase, summed over the workgroups of a launch (one copy per translation
+// unit; conv_sw.hip reports its own through fp_dbg_conv_sw): [0] row tables + barrier, [1] residual requests, [2] accumulators ->
+// E tile + barrier, [3] E tile -> stores issued (waits for the residual rows), [4] calls
+static __device__ unsigned long long ig_epi_dbg[8];
+#define IG_CLK(t) const unsigned long long t = wall_clock64()
+#else
+#define IG_CLK(t)
+#endif
+
 #define IG_VEC_FLOATS 256                       // per-channel epilogue vectors in LDS: bias | BatchNorm scale | BatchNorm shift
 #define IG_BIAS_LDS (3 * IG_VEC_FLOATS * 4)
 
@@ -33,6 +43,7 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
   const bool round_acc = p.round_acc != 0, has_bn = p.bn_scale != nullptr;
   long long* rowY = reinterpret_cast<long long*>(smem + BM * 2 * BN);
   long long* rowR = rowY + BM;
+  IG_CLK(te0);
   for (int r = tid; r < BM; r += THREADS) {
     const int m = m0 + r;
     const bool in = m < p.M;
@@ -40,6 +51,7 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
     if (p.R) rowR[r] = in ? ig_row_off(p.res, m) + n0 : 0;
   }
   __syncthreads();
+  IG_CLK(te1);
   // The residual rows are requested before the transposition: their HBM latency overlaps it
   half8 rv[NIT];
   if (p.R) {
@@ -50,6 +62,7 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
       if (FULL || rowY[ml] >= 0) rv[it] = *reinterpret_cast<const half8*>(p.R + rowR[ml] + ch * 8);
     }
   }
+  IG_CLK(te2);
   // D[i = channel][j = pixel]: lane holds pixel (lane & 31), channels 8g + 4*(lane>>5) + {0..3}, g = reg >> 2
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -96,6 +109,7 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
     }
   }
   __syncthreads();
+  IG_CLK(te3);
   const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -117,6 +131,13 @@ __device__ __forceinline__ void ig_epilogue_body(const IgemmParams& p, float16_ 
       *reinterpret_cast<half8*>(p.Ype + (size_t)m * p.N + n0 + ch * 8) = w;
     }
   }
+#ifdef FP_PROFILE_BUILD
+  IG_CLK(te4);
+  if (tid == 0) {
+    atomicAdd(&ig_epi_dbg[0], te1 - te0); atomicAdd(&ig_epi_dbg[1], te2 - te1); atomicAdd(&ig_epi_dbg[2], te3 - te2);
+    atomicAdd(&ig_epi_dbg[3], te4 - te3); atomicAdd(&ig_epi_dbg[4], 1ull);
+  }
+#endif
 }
 
 template <int BM, int BN, int TM, int THREADS, int DBG = 0>

@@ -127,7 +127,6 @@ def crop_windows(poses, K, mesh_diameter, crop_ratio, out_size=(160, 160)):
 
 
 _WS = {}
-_WS_IN_GRAPHS = []
 
 
 def workspace_bytes(N, V, T, oh=160, ow=160):
@@ -135,21 +134,22 @@ def workspace_bytes(N, V, T, oh=160, ow=160):
 
 
 def _workspace(nbytes, device):
-    """library-side default scratch: one per (device, stream) -- launches on different streams may overlap"""
+    """library-side default scratch: one per (device, stream) -- launches on different streams may overlap.
+
+    Inside a stream capture the stream-keyed scratch is NEVER handed out (round 5, the advisor's finding: torch.cuda.graph uses one
+    shared capture stream, so two graphs captured one after the other baked in the SAME scratch address; replayed on different
+    streams -- the PartGraphs pattern -- they raced on it and tri_id / zbuf came out silently wrong).  A capture without a caller-owned
+    `workspace` gets a fresh allocation made inside the capture: it comes from the capturing graph's private pool, lives exactly as
+    long as that graph, and no other graph or eager launch can hold its address."""
     if nbytes == 0:
         return None
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
-    capturing = torch.cuda.is_current_stream_capturing()
     if ws is None or ws.numel() < nbytes:
-        if capturing:
-            # an allocation made here would come from the capturing graph's private pool and then be cached process-wide
-            raise _lib.FpAmdError("render_crops inside a stream capture needs a caller-owned `workspace` (ops.workspace_bytes) "
-                                  "or a default scratch that is already large enough")
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _WS[key] = ws
-    elif capturing:
-        _WS_IN_GRAPHS.append(ws)      # a graph now holds its address: kept alive even if a larger scratch replaces it later
     return ws
 
 

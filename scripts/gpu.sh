@@ -42,6 +42,24 @@ t_ab() {      # same box, back to back: product, lock-step two-per-CU conv (make
   bench_line streams3 $PWD/$CS/libfp_amd.so --streams 3
   bench_line product_again $PWD/$CS/libfp_amd.so
 }
+t_libs() {    # LIBS="product dmac1 ...": per build the output hashes of the 3x3 convs, per-layer rates at N = 126 / 252, the step
+  for name in $LIBS; do
+    local lib=$PWD/$CS/libfp_amd_$name.so; [ $name = product ] && lib=$PWD/$CS/libfp_amd.so
+    echo "-- $name"
+    FP_AMD_LIB=$lib timeout 120 python scripts/cmp_conv_sw.py 2> /dev/null | sha1sum | cut -c1-16 | sed 's/^/   outputs sha1 /'
+    for n in 126 252; do
+      FP_N=$n FP_AMD_LIB=$lib timeout 120 python scripts/bench_igemm.py 2> /dev/null > $O/${TAG}_igemm_${name}_$n.log
+      python - $O/${TAG}_igemm_${name}_$n.log $n <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
+pick = lambda name, res: next((r["TFLOPs"] for r in rows if r["layer"] == name and r.get("residual", res) == res), 0)
+print(f"   N={sys.argv[2]}: 128->128 {pick('stem 128->128', False):.0f}/{pick('stem 128->128', True):.0f}  256->256 {pick('joint 256->256', False):.0f}/{pick('joint 256->256', True):.0f}  "
+      f"512->512 {pick('joint 512->512', False):.0f}/{pick('joint 512->512', True):.0f}  weighted {rows[-3]['TFLOPs'] if len(rows) > 3 else 0:.0f} TFLOP/s (no residual / residual)")
+PY
+    done
+    bench_line $name $lib
+  done
+}
 t_probe() {   # MFMA / VALU co-issue probe (scripts/mfma_valu_overlap)
   hipcc --offload-arch=gfx950 -O3 -pthread -o /tmp/mvprobe scripts/mfma_valu_overlap/probe.hip && timeout 300 /tmp/mvprobe > $O/${TAG}_mfma_valu_probe.log 2>&1; cat $O/${TAG}_mfma_valu_probe.log
 }

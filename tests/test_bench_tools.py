@@ -76,3 +76,50 @@ def test_packed_fp32_build_check_catches_a_packed_kernel(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", str(src), "-o", str(so)])
     r = subprocess.run([sys.executable, chk, str(so)], capture_output=True, text=True)
     assert r.returncode != 0 and "packed-fp32" in (r.stderr + r.stdout), (r.stdout, r.stderr)
+
+
+def test_bench_respawn_builds_the_launcher_command_line(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run, one rank per GPU on 127.0.0.1
+    (the driver's own launch line for N > 1); no 8-GPU node was ever available to the builder, so the command line is pinned here"""
+    import argparse
+    import subprocess
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--mode", "hypothesis"])
+    try:
+        bench._respawn(argparse.Namespace(gpus=8))
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 <= int(cmd[cmd.index("--master-port") + 1]) < 65536
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "3", "--mode", "hypothesis"]      # every flag reaches every rank
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                                 # dmabuf IPC: RCCL needs it on this host driver
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """on a node with fewer GPUs than --gpus the bench exits non-zero with the documented message instead of running fewer ranks
+    (this container has no GPU at all; on the 1-GPU box: profiles/r02_g_bench_gpus2_on_1gpu_box.log)"""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("this node has 8 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode != 0
+    assert "--gpus 8 requested but this node exposes" in r.stderr and "refusing to run fewer ranks" in r.stderr
+    # under a launcher the world size has to match
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=4" in r.stderr
