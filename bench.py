@@ -501,10 +501,12 @@ def main():
         # the same launches (same sub-batches, same sizes), but issued on ONE stream: a HIP-event pair around a kernel that
         # shares the chip with another stream's kernels measures the mix, not the kernel
         refiner.sub.serial = scorer.sub.serial = True
-        with timers:
-            for _ in range(args.steps):
-                step()
-        sync()
+        clock_instr = ClockSampler(local_rank)
+        with clock_instr:
+            with timers:
+                for _ in range(args.steps):
+                    step()
+            sync()
         refiner.sub.serial = scorer.sub.serial = args.serialize
     # third pass, only when the step is split: the same kernels in ONE launch sequence over all hypotheses -- the launch
     # sizes of `--streams 1` and of rounds 1 / 2a, for a like-for-like per-launch figure of the dominant kernel
@@ -574,6 +576,7 @@ def main():
                                     "region (foundationpose_amd/overlap.py); the per-kernel table and `roofline` time the same "
                                     "launches issued on one stream"},
             "clock": clock.summary(),
+            "energy": None,
             "register_path": None if dt_reg is None else {
                 "ms_per_step": dt_reg / args.steps * 1e3, "value": total_hyps * args.steps / dt_reg,
                 "note": "the same step as estimater.register() issues it (shared_translation=True: one observed crop per sub-batch in the "
@@ -581,6 +584,13 @@ def main():
             "network_mfma": {"algorithmic_TFLOP_per_step": flops / 1e3, "achieved_TFLOPs": flops / 1e3 / (dt / args.steps),
                              "frac_of_mfma_peak": flops / 1e3 / (dt / args.steps) / (MFMA_PEAK_TFLOPS * world)},
         }
+        pw = out["clock"].get("power_W_mean")
+        if pw and out["clock"].get("source_matches_torch_device_pci"):
+            # the step is power-limited: energy is the number a faster schedule has to move, not only time
+            j_step = pw * world * (dt / args.steps)
+            out["energy"] = {"socket_power_W_mean": pw, "J_per_step": j_step, "J_per_hypothesis": j_step / total_hyps,
+                             "hypotheses_per_joule": total_hyps / j_step, "pJ_per_network_flop": j_step / (flops * 1e9) * 1e12,
+                             "note": "amdgpu hwmon socket power sampled every 5 ms through the timed region x step time"}
         if not args.no_kernel_table:
             ksum = timers.summary()
             kern = {}
@@ -651,6 +661,14 @@ def main():
             out["stage_raster_crop"] = {"bytes_per_pass": stage_bytes, "ms_per_pass": r_ms + w_ms,
                                         "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,
                                         "frac_of_hbm_peak": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # at-clock fractions per kernel: the instrumented pass runs one stream at a higher clock than the timed region (less power), so
+            # each MFMA-bound entry point is also priced against 2.5 PFLOP/s x (clock sampled during THAT pass) / 2.4 GHz
+            ci = clock_instr.summary()
+            if ci.get("sclk_MHz_mean") and ci.get("source_matches_torch_device_pci"):
+                for name, ent in kern.items():
+                    if "TFLOPs" in ent:
+                        ent["frac_mfma_at_clock"] = ent["TFLOPs"] / (MFMA_PEAK_TFLOPS * ci["sclk_MHz_mean"] / 2400.0)
+                out["clock_instrumented_pass"] = {"sclk_MHz_mean": ci["sclk_MHz_mean"], "power_W_mean": ci.get("power_W_mean")}
             out["kernels"] = kern
             # per-stage rates ("reported separately"): launch time of a stage's entry points per step, one stream, and the
             # hypothesis-passes/s the stage would sustain alone (a pass = one hypothesis through one refine iteration or the score pass)

@@ -10,6 +10,7 @@ import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime with PyTo
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FP_AMD_LIB") or os.path.join(_HERE, "csrc", "libfp_amd.so")   # FP_AMD_LIB: A/B builds
+ABI_VERSION = 210    # = FP_AMD_ABI_VERSION of include/fp_amd.h (tests/test_abi.py keeps the two in step)
 _lib = None
 
 vp, ci, cf, cd, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -61,6 +62,10 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is absent: loud by design
             fn.restype = res
             fn.argtypes = args
+        got = int(handle.fp_version())
+        if got != ABI_VERSION:
+            raise FpAmdError(f"{LIB_PATH} reports ABI version {got}, this binding was written for {ABI_VERSION}: rebuild the library "
+                             f"(`make -C foundationpose_amd/csrc`) -- entry points changed meaning between versions (include/fp_amd.h)")
         _lib = handle
     return _lib
 

@@ -15,7 +15,7 @@ void fp_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fp_last_error(void) { return g_err; }
-extern "C" int fp_version(void) { return 200; }
+extern "C" int fp_version(void) { return FP_AMD_ABI_VERSION; }
 
 extern "C" int fp_mesh_create(const float* pos, const float* nrm, const int32_t* faces, const float* uv,
                               const int32_t* uv_idx, const float* tex, const float* vcol, int V, int T, int Ht,

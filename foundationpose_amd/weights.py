@@ -73,14 +73,19 @@ def fill_state_dict(template, seed=0, head_gain=1.0):
     return out
 
 
-def random_state_dict(kind, cfg=None, seed=0, head_scale=1.0):
+def random_state_dict(kind, cfg=None, seed=0, head_scale=1.0, heads="random"):
     """kind in {'refine','score'} -> seeded state_dict for RefineNet / ScoreNetMultiPair.
 
     head_scale multiplies the refiner's output heads (trans_head.1 / rot_head.1 weight and bias).  A TRAINED refiner is
     a contraction (its update shrinks the pose error); these untrained stand-ins are the opposite -- d(update)/d(pose)
     is ~40-120 for the seed-0 checkpoint on the synthetic scene (measured with the CPU oracle), so a
     free-running chain of iterations amplifies any last-bit difference into a different trajectory.  head_scale < ~0.008
-    makes the iteration map non-expanding; the free-running parity tests use CONTRACTION_HEAD_SCALE."""
+    makes the iteration map non-expanding; the free-running parity tests use CONTRACTION_HEAD_SCALE.
+
+    heads="fitted" (round 5; refiner, seed 0 only): the two final Linear(512 -> 3) layers come from a ridge regression of the pose
+    error on the pooled features of THIS seeded network over perturbations of the synthetic scene's ground-truth pose
+    (tests/golden/fit_contraction_heads.py -> data/standin_fitted_heads.npz): a genuine contraction towards the observed pose with
+    full-size first updates (rotation up to rot_normalizer, translation up to ~3 cm), instead of down-scaled random heads."""
     from .refine_network import RefineNet
     from .score_network import ScoreNetMultiPair
     if kind == "refine":
@@ -100,6 +105,16 @@ def random_state_dict(kind, cfg=None, seed=0, head_scale=1.0):
     sd = fill_state_dict(template, seed=seed, head_gain=1.0 if calibrated else gain)
     if calibrated:
         sd.update(_calibration_overlay(kind, sd))
+    if heads == "fitted":
+        if not (kind == "refine" and calibrated):
+            raise ValueError("heads='fitted' exists for the calibrated seed-0 refiner only")
+        import numpy as np
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "standin_fitted_heads.npz")
+        fit = np.load(path)
+        for k in ("trans_head.1.weight", "trans_head.1.bias", "rot_head.1.weight", "rot_head.1.bias"):
+            sd[k] = torch.from_numpy(fit[k]).to(sd[k].dtype).reshape(sd[k].shape)
+    elif heads != "random":
+        raise ValueError(heads)
     if kind == "refine" and head_scale != 1.0:
         for k in ("trans_head.1.weight", "trans_head.1.bias", "rot_head.1.weight", "rot_head.1.bias"):
             sd[k] = sd[k] * float(head_scale)

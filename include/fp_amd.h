@@ -56,6 +56,11 @@ typedef enum {
 typedef struct fp_mesh fp_mesh; /* opaque: device pointers + sizes of one object's mesh tensors */
 
 const char* fp_last_error(void);
+/* ABI version of the library = FP_AMD_ABI_VERSION of the header it was built from; a binding compares the two at load time
+ * (foundationpose_amd/_lib.py does and refuses a mismatch).  History of breaks that kept a symbol's name:
+ *   200 -> 210 (round 4 / 5): fp_linear_layernorm_fwd takes the FRAGMENT-PACKED weight (fp_pack_linear512_f16) and requires K = 512;
+ *                             a caller that still passes the nn.Linear-layout weight gets FP_OK and garbage -- check the version. */
+#define FP_AMD_ABI_VERSION 210
 int fp_version(void);
 
 /* Utils.py:104-130 make_mesh_tensors: records caller-owned device tensors.

@@ -63,6 +63,9 @@ PY
 t_probe() {   # MFMA / VALU co-issue probe (scripts/mfma_valu_overlap)
   hipcc --offload-arch=gfx950 -O3 -pthread -o /tmp/mvprobe scripts/mfma_valu_overlap/probe.hip && timeout 300 /tmp/mvprobe > $O/${TAG}_mfma_valu_probe.log 2>&1; cat $O/${TAG}_mfma_valu_probe.log
 }
+t_amp_fast() {   # the kernel-level policy tests (bit-identity / flip-rate gates of the GEMM family, plans against the oracle)
+  timeout 600 python -m pytest tests/test_gpu_amp.py -m gpu -q --timeout 600 -x -k "policy or encoder or plans" 2>&1 | tail -4 | cut -c1-300
+}
 t_conv_phases() {
   FP_AMD_LIB=$PWD/$CS/libfp_amd_profile.so timeout 300 python scripts/dbg_conv_sw_step.py 2> /dev/null | tee $O/${TAG}_conv_sw_step_phases.log
   FP_AMD_LIB=$PWD/$CS/libfp_amd_profile.so timeout 300 python scripts/dbg_conv_sw.py 2> /dev/null | tee $O/${TAG}_conv_sw_phases.log

@@ -20,7 +20,12 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in fp_amd.h but not exported by libfp_amd.so"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in foundationpose_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.fp_version() >= 100
+    # the ABI version: header, library and binding agree (round 5: fp_linear_layernorm_fwd changed the meaning of its weight argument
+    # under an unchanged name -- an external caller can only notice through the version)
+    import re
+    hdr = open(os.path.join(ROOT, "include", "fp_amd.h")).read()
+    ver = int(re.search(r"#define\s+FP_AMD_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.fp_version() == ver == _lib.ABI_VERSION and ver >= 210
 
 
 def test_argument_errors_are_reported_without_gpu():

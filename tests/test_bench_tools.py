@@ -76,6 +76,15 @@ def test_packed_fp32_build_check_catches_a_packed_kernel(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", str(src), "-o", str(so)])
     r = subprocess.run([sys.executable, chk, str(so)], capture_output=True, text=True)
     assert r.returncode != 0 and "packed-fp32" in (r.stderr + r.stdout), (r.stdout, r.stderr)
+    # round 5: a library the check cannot look into (here: no device code at all) FAILS instead of warning; the skip is opt-in
+    host = tmp_path / "host.c"
+    host.write_text("int f(void) { return 1; }\n")
+    hso = tmp_path / "libhost.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(host), "-o", str(hso)])
+    r = subprocess.run([sys.executable, chk, str(hso)], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "FP_AMD_ALLOW_UNCHECKED"})
+    assert r.returncode != 0 and "could not run" in (r.stderr + r.stdout), (r.stdout, r.stderr)
+    r = subprocess.run([sys.executable, chk, str(hso)], capture_output=True, text=True, env=dict(os.environ, FP_AMD_ALLOW_UNCHECKED="1"))
+    assert r.returncode == 0 and "skipped" in r.stderr
 
 
 def test_bench_respawn_builds_the_launcher_command_line(monkeypatch):

@@ -1225,3 +1225,125 @@ def test_network_kernels_write_only_their_outputs(dev):
                               yv.view(torch.float16).reshape(Bn, 82, 82, 64), 1)
         torch.cuda.synchronize()
         assert intact(a, nb), ("conv1", Bn)
+
+
+# ------------------------------------------------------------------ round 5: a15 ranking and the reference's track_one, against the oracle
+def test_register_ranking_and_track_one_match_the_oracle(scene, dev):
+    """SURVEY a15 (predict_score.py:174-175 / estimater.py:173-182: scores -> argsort -> poses[ids], best pose through the centring
+    transform) and the reference's tracking call (estimater.py:250-268: ONE hypothesis, 2 iterations, depth2xyzmap_batch), both through
+    the estimator facade in the fp32 configuration, against the CPU oracle run on the same hypotheses: the whole ranking, not only
+    "scores are sorted"; and track_one against the oracle's own two-iteration chain from the registered pose."""
+    from foundationpose_amd.estimater import FoundationPose
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.predict_score import ScorePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, DEFAULT_SCORE_CFG, random_state_dict
+    from oracle import ops as oo
+    from oracle import pipeline as op
+    mesh = scene["mesh"]
+    rcfg, scfg = dict(DEFAULT_REFINE_CFG), dict(DEFAULT_SCORE_CFG)
+    rsd, ssd = random_state_dict("refine", rcfg, seed=0), random_state_dict("score", scfg, seed=0)
+    refiner = PoseRefinePredictor(cfg=rcfg, state_dict=rsd, device=dev, precision="fp32")
+    scorer = ScorePredictor(cfg=scfg, state_dict=ssd, device=dev, precision="fp32")
+    est = FoundationPose(model_pts=mesh.vertices, model_normals=mesh.vertex_normals, mesh=mesh, scorer=scorer, refiner=refiner, device=dev)
+    est.track_graph = False
+    est.rot_grid = est.rot_grid[::8].contiguous()                  # 32 of the 252 hypotheses: the oracle finishes in seconds
+    n = est.rot_grid.shape[0]
+    K = scene["K"]
+    best = est.register(K=K, rgb=scene["rgb"], depth=scene["depth"], ob_mask=scene["mask"], iteration=1)
+    # the oracle on the SAME filtered depth and the SAME start hypotheses (the depth filters and the hypothesis generation are pinned
+    # by their own tests; the bilateral filter's expf differs by ulps between libm and the GPU, and a 1e-6 difference of the start
+    # translation is enough to flip coverage pixels of the stand-in network's inputs)
+    from foundationpose_amd import ops
+    depth_t = ops.bilateral_filter_depth(ops.erode_depth(torch.as_tensor(scene["depth"], device=dev, dtype=torch.float).contiguous(), radius=2), radius=2)
+    d = depth_t.cpu().numpy()
+    start = est.generate_random_pose_hypo(K=K, rgb=scene["rgb"], depth=depth_t,
+                                          mask=torch.as_tensor(scene["mask"], device=dev) > 0).cpu().numpy()
+    xyz = oo.depth2xyzmap(d, K, f64_internal=True)
+    diam = float(est.diameter)
+    mnp = op.mesh_tensors_np(est.mesh)                             # the estimator's (centred) mesh
+    p_ref = op.refine_predict(rcfg, rsd, scene["rgb"], d, K, start, xyz, mnp, diam, iteration=1)
+    s_ref = op.score_predict(scfg, ssd, scene["rgb"], d, K, p_ref, mnp, diam)
+    ids = np.argsort(-s_ref, kind="stable")
+    sc, po = est.scores.cpu().numpy(), est.poses.cpu().numpy()
+    assert sc.shape == (n,) and po.shape == (n, 4, 4)
+    tol = 1e-3 * max(1.0, np.abs(s_ref - 100).max())
+    np.testing.assert_allclose(sc, s_ref[ids], atol=tol)           # the sorted scores ARE the oracle's sorted scores
+    # the ranking: identical wherever two neighbouring oracle scores are further apart than the score tolerance
+    gaps = -np.diff(s_ref[ids])
+    # position i of the product's order must hold oracle hypothesis ids[i] unless it sits in a run of near-ties
+    for i in range(n):
+        dR = _geodesic(po[i:i + 1, :3, :3], p_ref[ids[i]][None, :3, :3])[0]
+        dt = np.linalg.norm(po[i, :3, 3] - p_ref[ids[i], :3, 3])
+        tie = (i > 0 and gaps[i - 1] <= 2 * tol) or (i < n - 1 and gaps[i] <= 2 * tol)
+        assert tie or (dR <= 1e-4 and dt <= 1e-4), (i, int(ids[i]), dR, dt)
+    assert (gaps > 2 * tol).sum() >= n // 2, "the stand-in scores are too close together for a ranking test"
+    assert int(est.best_id) == int(ids[0]) or gaps[0] <= 2 * tol
+    np.testing.assert_allclose(best, po[0] @ est.get_tf_to_centered_mesh().cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(est.pose_last.cpu().numpy(), po[0], atol=0)
+    # ---- track_one: one hypothesis, two iterations, the batch variant of the back-projection; teacher-forced per iteration like
+    # test_refiner_fp32_matches_oracle (the stand-in map amplifies a last-bit difference of iteration 1 in iteration 2)
+    xyz_b = oo.depth2xyzmap(d, K, f64_internal=False)
+    trace = []
+    op.refine_predict(rcfg, rsd, scene["rgb"], d, K, po[:1], xyz_b, mnp, diam, iteration=2, trace=trace)
+    est.pose_last = torch.as_tensor(po[0], device=dev)
+    t1 = est.track_one(scene["rgb"], scene["depth"], K, iteration=1)
+    got1 = est.pose_last.cpu().numpy().reshape(4, 4)
+    assert _geodesic(got1[None, :3, :3], trace[0]["poses"][:, :3, :3])[0] <= 1e-4 and np.linalg.norm(got1[:3, 3] - trace[0]["poses"][0, :3, 3]) <= 1e-4
+    np.testing.assert_allclose(t1, got1 @ est.get_tf_to_centered_mesh().cpu().numpy(), atol=1e-6)
+    est.pose_last = torch.as_tensor(trace[0]["poses"][0], device=dev)         # iteration 2 from the oracle's pose after iteration 1
+    est.track_one(scene["rgb"], scene["depth"], K, iteration=1)
+    got2 = est.pose_last.cpu().numpy().reshape(4, 4)
+    assert _geodesic(got2[None, :3, :3], trace[1]["poses"][:, :3, :3])[0] <= 1e-4 and np.linalg.norm(got2[:3, 3] - trace[1]["poses"][0, :3, 3]) <= 1e-4
+    # and the two-iteration call is the chain of two one-iteration calls (device-resident loop == host-chained calls, bit for bit)
+    est.pose_last = torch.as_tensor(po[0], device=dev)
+    est.track_one(scene["rgb"], scene["depth"], K, iteration=2)
+    two = est.pose_last.clone()
+    est.pose_last = torch.as_tensor(po[0], device=dev)
+    est.track_one(scene["rgb"], scene["depth"], K, iteration=1)
+    est.track_one(scene["rgb"], scene["depth"], K, iteration=1)
+    assert torch.equal(two, est.pose_last)
+
+
+def test_captured_renders_without_a_workspace_do_not_share_scratch(scene, dev, gmesh):
+    """the advisor's round-4 finding: two graphs captured one after the other (torch.cuda.graph uses ONE capture stream) baked in the
+    same stream-keyed default scratch; replayed on different streams they raced on it.  Now a capture without a caller-owned
+    workspace allocates its scratch inside the capture (the graph's private pool): two such graphs replayed concurrently, many times,
+    return the bits of the eager launches."""
+    from foundationpose_amd import ops
+    from foundationpose_amd.Utils import get_mesh_handle
+    h = get_mesh_handle(gmesh)
+    K, diam = scene["K"], scene["diameter"]
+    sets = []
+    for a in (0, 40):
+        P = torch.as_tensor(scene["poses"][a:a + 40], device=dev)
+        _, bb = ops.crop_windows(P, K, diam, 1.2, (160, 160))
+        A = torch.zeros((40, 6, 160, 160), dtype=torch.float16, device=dev)
+        sets.append((P, bb, A))
+
+    def render(i):
+        P, bb, A = sets[i]
+        return ops.render_crops(h, P, bb, K, 480, 640, out_hw=(160, 160), mesh_diameter=diam, xyz_thr=0.001, normalize_xyz=True,
+                                A_out=A, want=("A",))
+    base = []
+    for i in range(2):
+        render(i)
+        base.append(sets[i][2].clone())
+    torch.cuda.synchronize()
+    graphs = []
+    for i in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            render(i)                                 # no workspace argument
+        graphs.append(g)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    bad = 0
+    for rep in range(60):
+        for i in range(2):
+            sets[i][2].zero_()
+        torch.cuda.synchronize()
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                graphs[i].replay()
+        torch.cuda.synchronize()
+        bad += int(any(not torch.equal(sets[i][2], base[i]) for i in range(2)))
+    assert bad == 0, f"{bad} of 60 concurrent replays differ from the eager launches"
