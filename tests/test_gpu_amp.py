@@ -546,6 +546,73 @@ def test_refiner_contraction_chain_vs_exact(scene, dev, gmesh, frame, acc64):
     assert np.abs(Rd @ Rd.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
 
 
+FITTED_GATES = dict(tf_median_rad=6e-4, tf_max_rad=3e-3, tf_median_m=5e-5)
+
+
+def test_refiner_fitted_heads_chain_vs_exact(scene, dev, gmesh, frame):
+    """Round 5 (the round-4 verdict's item 5): a stand-in refiner whose two output heads are FITTED (ridge regression of the pose error
+    on the pooled features of the seeded network over perturbations of the ground-truth pose: weights.random_state_dict(heads=
+    "fitted"), tests/golden/fit_contraction_heads.py) -- realistic head norms (|W_rot| 1.4, |W_trans| 0.34 against the random heads'
+    5.6 / 2.3) and full-size, DIRECTED first updates (0.077 rad / 8 mm median) -- against the exactly-rounded chain
+    (tests/golden/acc64_fitted_chain_golden.npz) from 252 starts up to 15 deg / 2 cm off the ground truth.
+      (a) it refines: one iteration shrinks the translation error to the ground truth to a third and the rotation error by a fifth,
+          on the exact chain and on the deployed kernels alike;
+      (b) teacher-forced, all 252 x 5: the HIP plan is as close to the exactly-rounded pose as the fp32-accumulating CPU oracle
+          (EXACT_GATE on the medians of iteration 0, where the golden holds the oracle's sample), 2-3e-4 rad at these head norms;
+      (c) what the verdict asked for -- the FREE-RUNNING chain within 1e-4 rad of the exact one without down-scaled heads -- is
+          measured and NOT attainable with a random convolutional trunk: the golden's own fp32-accumulating oracle chain is 2.8e-4
+          rad from the exact one after iteration 1, 9.5e-3 after 2, 5e-2 after 3 and 9e-2 after 5 (x 30 per iteration: a
+          1e-6 pose difference flips coverage / nearest-neighbour pixels of the inputs, and untrained features are not smooth in
+          them), whatever the heads.  Asserted is therefore only that the deployed chain spreads no further than that oracle chain
+          does; the pose-level 1e-4 gate on a free-running chain stays with test_refiner_contraction_chain_vs_exact."""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    from oracle import pipeline as op
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "acc64_fitted_chain_golden.npz")))
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = random_state_dict("refine", cfg, seed=0, heads="fitted")
+    chain, ochain, P0, gt = g["chain"], g["oracle_chain"], g["start"], g["gt"]
+    A, B, _, _ = op.refine_inputs(cfg, P0, scene["mesh_np"], scene["rgb"], frame["xyz"], scene["K"], scene["diameter"])
+    assert (_crc(A), _crc(B)) == tuple(int(v) for v in g["crc"][0]), "this box's CPU builds other network inputs than the golden's"
+    pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16")
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+
+    def run(P, it):
+        o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P, frame["xyz_t"], iteration=it, **kw)
+        return o.cpu().numpy()
+    G = np.tile(gt[None], (len(P0), 1, 1)).astype(np.float32)
+    err = lambda P: _dist(P, G)
+    rep = dict(error_to_gt_start=dict(dR=_pct(err(P0)[0]), dt=_pct(err(P0)[1])),
+               error_to_gt_exact_chain=[dict(dR=_pct(err(chain[k])[0]), dt=_pct(err(chain[k])[1])) for k in range(1, 6)],
+               update_per_iteration=[dict(dR=_pct(_dist(chain[k + 1], chain[k])[0]), dt=_pct(_dist(chain[k + 1], chain[k])[1])) for k in range(5)])
+    # (b) teacher forced along the exact chain
+    tf = [run(chain[k], 1) for k in range(5)]
+    tfR = np.stack([_dist(tf[k], chain[k + 1])[0] for k in range(5)])
+    tft = np.stack([_dist(tf[k], chain[k + 1])[1] for k in range(5)])
+    oR0, ot0 = _dist(ochain[1], chain[1])      # the oracle's first iteration starts from the exact chain's poses: its teacher-forced sample
+    rep.update(teacher_forced_hip=dict(dR=_pct(tfR), dt=_pct(tft), dR_iteration0=_pct(tfR[0]), dt_iteration0=_pct(tft[0])),
+               teacher_forced_oracle_iteration0=dict(dR=_pct(oR0), dt=_pct(ot0)))
+    # (c) free running
+    out5 = run(P0, 5)
+    frR, frt = _dist(out5, chain[5])
+    ofR, oft = _dist(ochain[5], chain[5])
+    rep.update(free_running_hip=dict(dR=_pct(frR), dt=_pct(frt)), free_running_oracle=dict(dR=_pct(ofR), dt=_pct(oft)),
+               free_running_oracle_by_iteration=[_pct(_dist(ochain[k], chain[k])[0]) for k in range(1, 6)],
+               error_to_gt_deployed_chain=dict(dR=_pct(err(out5)[0]), dt=_pct(err(out5)[1])))
+    REPORT["refiner_252_fitted_heads_chain_vs_exact"] = rep
+    # (a) full-size, directed first updates
+    e0, e1, h1 = err(P0), err(chain[1]), err(tf[0])
+    assert rep["update_per_iteration"][0]["dR"]["median"] > 0.04 and rep["update_per_iteration"][0]["dt"]["median"] > 4e-3, rep
+    assert np.median(e1[1]) < 0.5 * np.median(e0[1]) and np.median(e1[0]) < 0.9 * np.median(e0[0]), rep
+    assert np.median(h1[1]) < 0.5 * np.median(e0[1]) and np.median(h1[0]) < 0.9 * np.median(e0[0]), rep
+    # (b)
+    assert np.median(tfR[0]) <= EXACT_GATE * np.median(oR0) and np.percentile(tfR[0], 90) <= EXACT_GATE * np.percentile(oR0, 90), rep
+    assert np.median(tft[0]) <= EXACT_GATE * np.median(ot0) and tfR[0].max() <= EXACT_GATE_MAX * oR0.max(), rep
+    assert np.median(tfR) <= FITTED_GATES["tf_median_rad"] and tfR.max() <= FITTED_GATES["tf_max_rad"] and np.median(tft) <= FITTED_GATES["tf_median_m"], rep
+    # (c) no further from the exact chain than the fp32-accumulating oracle chain is (both have left it: see the docstring)
+    assert np.median(frR) <= 1.5 * np.median(ofR) and np.median(frt) <= 1.5 * np.median(oft), rep
+
+
 def test_scorer_252_vs_exact(scene, dev, gmesh, frame, acc64):
     """the 252 scores of the exact chain's refined poses: HIP plan, fp32-accumulating oracle and PyTorch-ROCm under autocast,
     each against the exactly-rounded scores (acc64 score_exact): logit errors, Kendall tau, top-1.  Gate: hip as close to the

@@ -1262,22 +1262,30 @@ def test_register_ranking_and_track_one_match_the_oracle(scene, dev):
     diam = float(est.diameter)
     mnp = op.mesh_tensors_np(est.mesh)                             # the estimator's (centred) mesh
     p_ref = op.refine_predict(rcfg, rsd, scene["rgb"], d, K, start, xyz, mnp, diam, iteration=1)
-    s_ref = op.score_predict(scfg, ssd, scene["rgb"], d, K, p_ref, mnp, diam)
+    # the refined poses register() ranked, before ranking: the same predict call once more (same kernels, same bits)
+    xyz_t = ops.depth_to_xyz(depth_t, K, zfar=float("inf"), f64_internal=True)
+    p_hip, _ = refiner.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=scene["rgb"], depth=depth_t, K=K,
+                               ob_in_cams=torch.as_tensor(start, device=dev), xyz_map=xyz_t, mesh_diameter=diam, iteration=1,
+                               shared_translation=True)
+    p_hip = p_hip.cpu().numpy()
+    assert _geodesic(p_hip[:, :3, :3], p_ref[:, :3, :3]).max() <= 1e-4 and np.linalg.norm(p_hip[:, :3, 3] - p_ref[:, :3, 3], axis=1).max() <= 1e-4
+    # the oracle scores THOSE poses (teacher forced: the stand-in scorer turns a 4e-6 pose difference into score differences of
+    # up to 1.6 through coverage / nearest-neighbour flips of its inputs, measured; the ranking logic is what is under test here)
+    s_ref = op.score_predict(scfg, ssd, scene["rgb"], d, K, p_hip, mnp, diam)
     ids = np.argsort(-s_ref, kind="stable")
     sc, po = est.scores.cpu().numpy(), est.poses.cpu().numpy()
     assert sc.shape == (n,) and po.shape == (n, 4, 4)
     tol = 1e-3 * max(1.0, np.abs(s_ref - 100).max())
     np.testing.assert_allclose(sc, s_ref[ids], atol=tol)           # the sorted scores ARE the oracle's sorted scores
-    # the ranking: identical wherever two neighbouring oracle scores are further apart than the score tolerance
+    assert (sc[:-1] >= sc[1:]).all()
+    # the ranking: position i holds oracle hypothesis ids[i] -- the very pose, bit for bit -- unless it sits in a run of near-ties
     gaps = -np.diff(s_ref[ids])
-    # position i of the product's order must hold oracle hypothesis ids[i] unless it sits in a run of near-ties
     for i in range(n):
-        dR = _geodesic(po[i:i + 1, :3, :3], p_ref[ids[i]][None, :3, :3])[0]
-        dt = np.linalg.norm(po[i, :3, 3] - p_ref[ids[i], :3, 3])
         tie = (i > 0 and gaps[i - 1] <= 2 * tol) or (i < n - 1 and gaps[i] <= 2 * tol)
-        assert tie or (dR <= 1e-4 and dt <= 1e-4), (i, int(ids[i]), dR, dt)
+        assert tie or np.array_equal(po[i], p_hip[ids[i]]), (i, int(ids[i]))
     assert (gaps > 2 * tol).sum() >= n // 2, "the stand-in scores are too close together for a ranking test"
     assert int(est.best_id) == int(ids[0]) or gaps[0] <= 2 * tol
+    assert sorted(map(bytes, po)) == sorted(map(bytes, p_hip))     # a permutation of the refined poses: nothing lost, nothing doubled
     np.testing.assert_allclose(best, po[0] @ est.get_tf_to_centered_mesh().cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(est.pose_last.cpu().numpy(), po[0], atol=0)
     # ---- track_one: one hypothesis, two iterations, the batch variant of the back-projection; teacher-forced per iteration like
