@@ -39,7 +39,10 @@ int fp_conv3x3_sw_tile_rows(const IgemmParams& p);
 // Measured at the bench shapes: the throughput follows the operand bytes per flop, not the schedule --
 // 4x2 MFMA tiles per wave (256x256 workgroup tile) halve the staged bytes per MFMA against 2x2 (128x128), and the
 // 128x128 variant makes up for it with two co-resident workgroups that fill each other's barrier and epilogue gaps.
-template <int BM, int BN, int TM, int NST, int BK>
+// SPLITK (round 5, fp_igemm_f16_splitk_fwd): grid.y = number of k ranges; workgroup (tile, split) multiplies k-steps
+// [split * nk / nsplit, (split + 1) * nk / nsplit) of its tile and leaves the fp32 accumulators in the slab, in fragment order (a
+// wave store = one contiguous KiB); k_splitk_epilogue adds the ranges in order and runs the epilogue arithmetic.
+template <int BM, int BN, int TM, int NST, int BK, bool SPLITK = false>
 __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, ((BM / (32 * TM)) * (BN / 64) == 4 && TM == 4) ? 2 : 1) void k_igemm_f16(IgemmParams p) {
   constexpr int NWN = BN / 64;
   constexpr int NW = (BM / (32 * TM)) * NWN;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, ((BM / (32 * TM)
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int Ktot = p.taps * p.Cin;
-  ig_bias_to_lds(p, n0, bias_lds, wid, lane);
+  if constexpr (!SPLITK) ig_bias_to_lds(p, n0, bias_lds, wid, lane);
 
   // ---- per-thread staging sources: wave w loads rows [8*AI*w, +8*AI) of the A tile and [8*WI*w, +8*WI) of the W tile.
   // Kept as 32-bit byte offsets from the (uniform) tensor bases, so that the per-k-step part of every address is a
@@ -94,10 +97,17 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, ((BM / (32 * TM)
     const int c = (lane % CPK) ^ swz(row);
     woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
   }
-  const int nk = p.taps * (p.Cin / BK);
+  int nk = p.taps * (p.Cin / BK);
   // running state of the NEXT k-step to stage: (ky, kx, ci0) advance without divisions; all scalar
   int st_ci0 = 0, st_kx = 0, st_ky = 0, st_k = 0;
   const int inWp = p.in.Wp, inCs = p.in.cstride, Cin = p.Cin;
+  if constexpr (SPLITK) {
+    const int split = blockIdx.y, cpt = Cin / BK;
+    const int ks0 = (int)(((long long)split * nk) / p.nsplit), ks1 = (int)(((long long)(split + 1) * nk) / p.nsplit);
+    const int tap = ks0 / cpt;
+    st_k = ks0; st_ci0 = (ks0 - tap * cpt) * BK; st_ky = tap / 3; st_kx = tap - 3 * st_ky;
+    nk = ks1 - ks0;
+  }
   // buffer descriptors (wave-uniform): LDS-DMA as `buffer_load_dwordx4 voff, rsrc, soff offen lds` -- per-lane byte
   // offset in a VGPR computed once, per-k-step offset in an SGPR, LDS destination in M0: no vector ALU work per load
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
@@ -187,6 +197,20 @@ __global__ __launch_bounds__((BM / (32 * TM)) * (BN / 64) * 64, ((BM / (32 * TM)
     buf = (buf + 1 == NST) ? 0 : buf + 1;
     nbuf = (nbuf + 1 == NST) ? 0 : nbuf + 1;
   }
+  if constexpr (SPLITK) {
+    typedef float float4_ __attribute__((ext_vector_type(4)));
+    float4_* dst = reinterpret_cast<float4_*>(p.slab) + ((((size_t)blockIdx.y * nwg + tile) * NW + wid) * (8 * TM)) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const float4_ v = {acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+          dst[((i * 4 + g) * TM + j) * 64] = v;
+        }
+    return;
+  }
   __syncthreads();   // all fragment reads done before the staging buffers become the transpose tile
 
   ig_epilogue<BM, BN, TM, THREADS, 0>(p, acc, smem, m0, n0, wm, wn, tid, lane, bias_lds);
@@ -202,6 +226,92 @@ static int ig_launch(const IgemmParams& p, hipStream_t stream) {
   FP_SET_MAX_LDS((k_igemm_f16<BM, BN, TM, NST, BK>), LDS);
   hipLaunchKernelGGL((k_igemm_f16<BM, BN, TM, NST, BK>), dim3((unsigned)tiles), dim3(THREADS), LDS, stream, p);
   FP_CHECK_LAUNCH("fp_igemm_f16_fwd");
+  return FP_OK;
+}
+
+// The second half of a split-K product: one thread per accumulator quad (4 consecutive channels of one pixel) adds the k ranges IN
+// RANGE ORDER (deterministic; another fp32 summation order than the unsplit kernel's) and applies the epilogue of
+// igemm_epilogue.h to its four values -- the same operations in the same order per element: bias / conv rounding / BatchNorm,
+// residual add as an IEEE half add, ReLU, the optional positional second output.
+template <int BM, int BN, int TM>
+__global__ __launch_bounds__(256) void k_splitk_epilogue(IgemmParams p, int ntiles) {
+  constexpr int NWN = BN / 64, NW = (BM / (32 * TM)) * NWN;
+  typedef float float4_ __attribute__((ext_vector_type(4)));
+  typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(t & 63);
+  size_t q = t >> 6;
+  const int j = (int)(q % TM); q /= TM;
+  const int g = (int)(q & 3); q >>= 2;
+  const int i = (int)(q & 1); q >>= 1;
+  const int wid = (int)(q % NW);
+  const int tile = (int)(q / NW);
+  if (tile >= ntiles) return;
+  const int tiles_n = p.N / BN;
+  const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+  const int wm = wid / NWN, wn = wid - wm * NWN;
+  const int m = bm * BM + wm * (32 * TM) + j * 32 + (lane & 31);
+  const int n = bn * BN + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
+  if (m >= p.M) return;
+  const float4_* src = reinterpret_cast<const float4_*>(p.slab) + t;
+  const size_t per_split = (size_t)ntiles * NW * (8 * TM) * 64;
+  float4_ a = src[0];
+  for (int s = 1; s < p.nsplit; ++s) {
+    const float4_ b = src[(size_t)s * per_split];
+    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+  }
+  float4_ bv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bv = *reinterpret_cast<const float4_*>(p.bias + n);
+  half4 v;
+  if (p.round_acc) {
+    const half2_ b01 = {(_Float16)bv[0], (_Float16)bv[1]}, b23 = {(_Float16)bv[2], (_Float16)bv[3]};
+    half2_ t01 = {(_Float16)a[0], (_Float16)a[1]};
+    half2_ t23 = {(_Float16)a[2], (_Float16)a[3]};
+    t01 = t01 + b01;
+    t23 = t23 + b23;
+    if (p.bn_scale) {
+      const float4_ sc = *reinterpret_cast<const float4_*>(p.bn_scale + n), sh = *reinterpret_cast<const float4_*>(p.bn_shift + n);
+      v[0] = (_Float16)fmaf((float)t01[0], sc[0], sh[0]);
+      v[1] = (_Float16)fmaf((float)t01[1], sc[1], sh[1]);
+      v[2] = (_Float16)fmaf((float)t23[0], sc[2], sh[2]);
+      v[3] = (_Float16)fmaf((float)t23[1], sc[3], sh[3]);
+    } else {
+      v[0] = t01[0]; v[1] = t01[1]; v[2] = t23[0]; v[3] = t23[1];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (_Float16)(a[e] + bv[e]);
+  }
+  if (p.R) v = v + *reinterpret_cast<const half4*>(p.R + ig_row_off(p.res, m) + n);
+  if (p.relu) {
+    const half4 zero = {0, 0, 0, 0};
+    v = __builtin_elementwise_max(v, zero);
+  }
+  *reinterpret_cast<half4*>(p.Y + ig_row_off(p.out, m) + n) = v;
+  if (p.Ype) {
+    const float4_ e0 = *reinterpret_cast<const float4_*>(p.pe + (size_t)(m % p.pe_period) * p.N + n);
+    half4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (_Float16)((float)v[e] + e0[e]);
+    *reinterpret_cast<half4*>(p.Ype + (size_t)m * p.N + n) = w;
+  }
+}
+
+// split-K always runs the 128 x 128 x 64 tile (4 waves, two stages): it exists for launches of a few dozen tiles
+constexpr int SK_BM = 128, SK_BN = 128, SK_TM = 2, SK_NST = 2, SK_BK = 64;
+static size_t ig_splitk_bytes(int M, int N, int splits) {
+  return (size_t)splits * fp_cdiv(M, SK_BM) * (N / SK_BN) * (size_t)(SK_BM * SK_BN * 4);
+}
+static int ig_launch_splitk(const IgemmParams& p, hipStream_t stream) {
+  constexpr int LDS = ig_lds_main<SK_BM, SK_BN>(SK_NST * (SK_BM + SK_BN) * SK_BK * 2) + IG_BIAS_LDS;
+  const long long tiles = (long long)fp_cdiv(p.M, SK_BM) * (p.N / SK_BN);
+  FP_REQUIRE(tiles * p.nsplit < (1ll << 31) && p.nsplit <= 65535, "fp_igemm_f16_splitk_fwd: too many tiles");
+  FP_SET_MAX_LDS((k_igemm_f16<SK_BM, SK_BN, SK_TM, SK_NST, SK_BK, true>), LDS);
+  hipLaunchKernelGGL((k_igemm_f16<SK_BM, SK_BN, SK_TM, SK_NST, SK_BK, true>), dim3((unsigned)tiles, (unsigned)p.nsplit), dim3(256), LDS, stream, p);
+  FP_CHECK_LAUNCH("fp_igemm_f16_splitk_fwd(partial products)");
+  const long long threads = tiles * 4 * (8 * SK_TM) * 64;
+  hipLaunchKernelGGL((k_splitk_epilogue<SK_BM, SK_BN, SK_TM>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p, (int)tiles);
+  FP_CHECK_LAUNCH("fp_igemm_f16_splitk_fwd(reduce + epilogue)");
   return FP_OK;
 }
 
@@ -274,10 +384,8 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
 }
 
 
-extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, const void* w, void* y, const fp_igemm_geom* y_geom,
-                                int M, int N, int Cin, int taps, const fp_igemm_epilogue* ep, void* stream) {
-  FP_REQUIRE(M >= 0, "fp_igemm_f16_fwd: M < 0");
-  if (M == 0) return FP_OK;
+static int ig_build_params(const void* x, const fp_igemm_geom* x_geom, const void* w, void* y, const fp_igemm_geom* y_geom,
+                           int M, int N, int Cin, int taps, const fp_igemm_epilogue* ep, IgemmParams& p) {
   FP_REQUIRE(x && w && y && x_geom && y_geom, "fp_igemm_f16_fwd: NULL tensor / geometry");
   FP_REQUIRE(taps == 1 || taps == 9, "fp_igemm_f16_fwd: taps must be 1 (GEMM) or 9 (3x3 conv), got %d", taps);
   FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
@@ -294,12 +402,44 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   if (int err = ig_check_geom(x_geom, "input")) return err;
   if (int err = ig_check_geom(y_geom, "output")) return err;
   if (e.residual) if (int err = ig_check_geom(e.r_geom, "residual")) return err;
-  IgemmParams p;
   p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = e.bias; p.bn_scale = e.bn_scale; p.bn_shift = e.bn_shift;
   p.R = (const _Float16*)e.residual; p.Y = (_Float16*)y;
   p.pe = e.pe; p.Ype = (_Float16*)e.y_pe; p.pe_period = e.pe_period;
   p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = (e.flags & FP_IGEMM_RELU) ? 1 : 0;
   p.round_acc = (e.flags & FP_IGEMM_ROUND_ACC) ? 1 : 0;
   p.in = ig_geom(x_geom); p.out = ig_geom(y_geom); p.res = e.residual ? ig_geom(e.r_geom) : ig_geom(y_geom);
+  p.slab = nullptr; p.nsplit = 0;
+  return FP_OK;
+}
+
+extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, const void* w, void* y, const fp_igemm_geom* y_geom,
+                                int M, int N, int Cin, int taps, const fp_igemm_epilogue* ep, void* stream) {
+  FP_REQUIRE(M >= 0, "fp_igemm_f16_fwd: M < 0");
+  if (M == 0) return FP_OK;
+  IgemmParams p;
+  if (int err = ig_build_params(x, x_geom, w, y, y_geom, M, N, Cin, taps, ep, p)) return err;
   return ig_dispatch(p, (hipStream_t)stream);
+}
+
+extern "C" size_t fp_igemm_splitk_workspace_bytes(int M, int N, int splits) {
+  if (M <= 0 || N <= 0 || N % SK_BN != 0 || splits <= 0) return 0;
+  return ig_splitk_bytes(M, N, splits);
+}
+
+extern "C" int fp_igemm_f16_splitk_fwd(const void* x, const fp_igemm_geom* x_geom, const void* w, void* y, const fp_igemm_geom* y_geom,
+                                       int M, int N, int Cin, int taps, const fp_igemm_epilogue* ep, int splits, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  FP_REQUIRE(M >= 0, "fp_igemm_f16_splitk_fwd: M < 0");
+  if (M == 0) return FP_OK;
+  IgemmParams p;
+  if (int err = ig_build_params(x, x_geom, w, y, y_geom, M, N, Cin, taps, ep, p)) return err;
+  const int nk = taps * (Cin / SK_BK);
+  FP_REQUIRE(splits >= 1 && splits <= nk, "fp_igemm_f16_splitk_fwd: splits=%d must be in [1, %d] (k-steps of 64)", splits, nk);
+  const size_t need = ig_splitk_bytes(M, N, splits);
+  if (!workspace || workspace_bytes < need || ((size_t)workspace & 15)) {
+    fp_set_error("fp_igemm_f16_splitk_fwd: workspace too small or unaligned (%zu < %zu bytes, see fp_igemm_splitk_workspace_bytes)", workspace_bytes, need);
+    return FP_ERR_WORKSPACE;
+  }
+  p.slab = (float*)workspace; p.nsplit = splits;
+  return ig_launch_splitk(p, (hipStream_t)stream);
 }

@@ -53,6 +53,8 @@ struct IgemmParams {
   int round_acc;        // FP_IGEMM_ROUND_ACC: the accumulator is rounded to fp16 BEFORE the bias is added (nn.Conv2d under
                         // autocast: ATen adds the bias to the fp16 convolution output); 0: one rounding of acc + bias (nn.Linear)
   IgemmGeom in, out, res;
+  float* slab;          // split-K only (fp_igemm_f16_splitk_fwd): fp32 partial accumulators in fragment order,
+  int nsplit;           //   [split][tile][wave][(i, g, j)][lane] x float4; 0 = not split
 };
 
 __device__ __forceinline__ long long ig_row_off(const IgemmGeom& g, int m) {

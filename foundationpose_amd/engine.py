@@ -193,6 +193,27 @@ def _conv_params(sd, conv_p, bn_p):
                 bias=None if b is None else _r16(b.float()), scale=scale, shift=shift)
 
 
+# Round 5: split-K for the reference's tracking call.  With ONE hypothesis (estimater.py:250-268) the encoder's convolutions are
+# launches of 16-26 tiles on 256 CUs, each tile running its whole k loop (55 us per launch on average, 73 % of track_one's GPU time);
+# fp_igemm_f16_splitk_fwd cuts the k range instead.  The decision depends on the HYPOTHESIS COUNT of the call only (not on the image
+# count of a launch: the shared-observed-crop form of the stem must keep the summation order of the plain form) and the number of
+# pieces is a constant of the layer, so sub-batches, the two-pose quirk and graph replays of one call all see the same arithmetic.
+# measured (scripts/bench_small_batches.py, profiles/r05_k_small_batches.log): predict(n, 2 iterations) 1.90 -> 1.05 ms at n = 1, 1.90 -> 1.21 at
+# 4, 1.93 -> 1.39 at 8, 2.02 -> 1.71 at 12, 2.05 -> 1.96 at 16, slower from 24 on.  Must stay below the sub-batch minimum (overlap.SubBatches
+# min_rows = 32): a call that is split into sub-batches never takes this path, so the parts of a call and the whole call always agree.
+SPLITK_MAX_HYPS = int(__import__("os").environ.get("FP_AMD_SPLITK_MAX_HYPS", "12"))
+SPLITK_TARGET_WGS = 384        # (tile, piece) workgroups a launch should have: 1.5 per CU
+
+
+def splitk_pieces(rows, cout, cin):
+    """pieces of the 9 * cin / 64 k-steps for a 3x3 convolution of `rows` output pixels: enough (tile, piece) workgroups to fill the
+    chip, at least two k-steps per piece.  A function of the layer and of the hypothesis count of the CALL (rows = images x pixels;
+    the shared-observed-crop stem passes the image count of the plain form), so every launch of one call sees the same pieces."""
+    tiles = -(-rows // 128) * (cout // 128)
+    nk = 9 * cin // 64
+    return max(1, min(nk // 2, round(SPLITK_TARGET_WGS / tiles)))
+
+
 class _HipEncoder:
     """The encoder on libfp_amd.so only: patch-embed conv (fp_conv7x7s2_bn_relu_fwd) + 15 implicit-GEMM 3x3 convs
     (fp_igemm_f16_fwd) with the conv / BatchNorm / residual / ReLU rounding sequence of autocast in their epilogues.
@@ -224,20 +245,32 @@ class _HipEncoder:
         if b is None:
             z = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=self.device)
             h1, w1, h2, w2, h3, w3 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
-            b = dict(P1=z(2 * n, h1 + 2, w1 + 2, 64), P2=z(2 * n, h2 + 2, w2 + 2, 128), P3=z(2 * n, h2 + 2, w2 + 2, 128),
+            sk = None
+            if n <= SPLITK_MAX_HYPS:
+                need = max(ops.igemm_splitk_workspace_bytes(r, co, splitk_pieces(r, co, ci))
+                           for r, co, ci in ((2 * n * h2 * w2, 128, 64), (2 * n * h2 * w2, 128, 128), (n * h2 * w2, 256, 256),
+                                             (n * h3 * w3, 512, 256), (n * h3 * w3, 512, 512)))
+                sk = torch.empty(need, dtype=torch.uint8, device=self.device)
+            b = dict(SK=sk, P1=z(2 * n, h1 + 2, w1 + 2, 64), P2=z(2 * n, h2 + 2, w2 + 2, 128), P3=z(2 * n, h2 + 2, w2 + 2, 128),
                      T=z(2 * n, h2 + 2, w2 + 2, 128), CAT=z(n, h2 + 2, w2 + 2, 256), J0=z(n, h2 + 2, w2 + 2, 256),
                      T2=z(n, h2 + 2, w2 + 2, 256), Q0=z(n, h3 + 2, w3 + 2, 512), Q1=z(n, h3 + 2, w3 + 2, 512),
                      T3=z(n, h3 + 2, w3 + 2, 512), dims=(h1, w1, h2, w2, h3, w3))
             self._bufs[key] = b
         return b
 
-    def _conv(self, name, x, Bn, Ho, Wo, Cin, Cout, y, stride=1, res=None, relu=True, gout=None, gres=None, pe=None, y_pe=None):
+    def _conv(self, name, x, Bn, Ho, Wo, Cin, Cout, y, stride=1, res=None, relu=True, gout=None, gres=None, pe=None, y_pe=None, sk=None,
+              sk_rows=None):
         c = self.w[name]
         G = ops.IgemmGeom.image
         gin = G(Ho, Wo, 1, Cin, stride=stride, offset=0)
         gout = gout if gout is not None else G(Ho, Wo, 1, Cout)
         if res is not None and gres is None:
             gres = G(Ho, Wo, 1, Cout)
+        if sk is not None:
+            return ops.igemm_f16_splitk(x, gin, c["w"], c["bias"], y, gout, Bn * Ho * Wo, Cout, Cin, 9,
+                                        splitk_pieces(sk_rows if sk_rows is not None else Bn * Ho * Wo, Cout, Cin), sk,
+                                        relu=relu, residual=res, r_geom=gres, bn_scale=c["scale"], bn_shift=c["shift"],
+                                        conv_rounding=True, pe=pe, y_pe=y_pe)
         return ops.igemm_f16(x, gin, c["w"], c["bias"], y, gout, Bn * Ho * Wo, Cout, Cin, 9, relu=relu, residual=res, r_geom=gres,
                              bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True, pe=pe, y_pe=y_pe)
 
@@ -254,27 +287,27 @@ class _HipEncoder:
         h1, w1, h2, w2, h3, w3 = b["dims"]
         G = ops.IgemmGeom.image
         ops.conv7x7s2_bn_relu(AB, self.c1_w, self.c1_b, self.c1_scale, self.c1_shift, b["P1"][:n2], 1)
-        self._conv("c2", b["P1"], n2, h2, w2, 64, 128, b["P2"], stride=2)
-        self._conv("s2a", b["P2"], n2, h2, w2, 128, 128, b["T"])
-        self._conv("s2b", b["T"], n2, h2, w2, 128, 128, b["P3"], res=b["P2"])
-        self._conv("s3a", b["P3"], n2, h2, w2, 128, 128, b["T"])
+        self._conv("c2", b["P1"], n2, h2, w2, 64, 128, b["P2"], stride=2, sk=b["SK"], sk_rows=2 * n * h2 * w2)
+        self._conv("s2a", b["P2"], n2, h2, w2, 128, 128, b["T"], sk=b["SK"], sk_rows=2 * n * h2 * w2)
+        self._conv("s2b", b["T"], n2, h2, w2, 128, 128, b["P3"], res=b["P2"], sk=b["SK"], sk_rows=2 * n * h2 * w2)
+        self._conv("s3a", b["P3"], n2, h2, w2, 128, 128, b["T"], sk=b["SK"], sk_rows=2 * n * h2 * w2)
         # stem output of image i (A) and image n+i (B) side by side along C: torch.cat((a, b), 1)
         self._conv("s3b", b["T"], n2, h2, w2, 128, 128, b["CAT"], res=b["P3"],
-                   gout=G(h2, w2, 1, 256, bsplit=n, cgroup=128), gres=G(h2, w2, 1, 128))
+                   gout=G(h2, w2, 1, 256, bsplit=n, cgroup=128), gres=G(h2, w2, 1, 128), sk=b["SK"], sk_rows=2 * n * h2 * w2)
         if shared_b and n > 1:
             ops.replicate_channels(b["CAT"], n, 128, 256)
-        self._conv("j0a", b["CAT"], n, h2, w2, 256, 256, b["T2"])
-        self._conv("j0b", b["T2"], n, h2, w2, 256, 256, b["J0"], res=b["CAT"])
-        self._conv("j1a", b["J0"], n, h2, w2, 256, 256, b["T2"])
-        self._conv("j1b", b["T2"], n, h2, w2, 256, 256, b["CAT"], res=b["J0"])
-        self._conv("j2", b["CAT"], n, h3, w3, 256, 512, b["Q0"], stride=2)
-        self._conv("j3a", b["Q0"], n, h3, w3, 512, 512, b["T3"])
-        self._conv("j3b", b["T3"], n, h3, w3, 512, 512, b["Q1"], res=b["Q0"])
-        self._conv("j4a", b["Q1"], n, h3, w3, 512, 512, b["T3"])
+        self._conv("j0a", b["CAT"], n, h2, w2, 256, 256, b["T2"], sk=b["SK"])
+        self._conv("j0b", b["T2"], n, h2, w2, 256, 256, b["J0"], res=b["CAT"], sk=b["SK"])
+        self._conv("j1a", b["J0"], n, h2, w2, 256, 256, b["T2"], sk=b["SK"])
+        self._conv("j1b", b["T2"], n, h2, w2, 256, 256, b["CAT"], res=b["J0"], sk=b["SK"])
+        self._conv("j2", b["CAT"], n, h3, w3, 256, 512, b["Q0"], stride=2, sk=b["SK"])
+        self._conv("j3a", b["Q0"], n, h3, w3, 512, 512, b["T3"], sk=b["SK"])
+        self._conv("j3b", b["T3"], n, h3, w3, 512, 512, b["Q1"], res=b["Q0"], sk=b["SK"])
+        self._conv("j4a", b["Q1"], n, h3, w3, 512, 512, b["T3"], sk=b["SK"])
         tok = torch.empty((n, h3 * w3, 512), dtype=torch.float16, device=AB.device)
         x16 = torch.empty_like(tok)
         self._conv("j4b", b["T3"], n, h3, w3, 512, 512, tok, res=b["Q1"], gout=G(h3, w3, 0, 512), gres=G(h3, w3, 1, 512),
-                   pe=self.pe[: h3 * w3], y_pe=x16)
+                   pe=self.pe[: h3 * w3], y_pe=x16, sk=b["SK"])
         return tok, x16
 
 

@@ -320,6 +320,36 @@ def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residu
     return y
 
 
+def igemm_splitk_workspace_bytes(M, N, splits):
+    return int(_lib.lib().fp_igemm_splitk_workspace_bytes(int(M), int(N), int(splits)))
+
+
+def igemm_f16_splitk(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, splits, workspace, relu=False, residual=None, r_geom=None,
+                     bn_scale=None, bn_shift=None, conv_rounding=False, pe=None, y_pe=None):
+    """igemm_f16 for launches of a few dozen tiles (one or two hypotheses: the reference's track_one): the k range in `splits`
+    pieces, partial sums through the caller-owned `workspace` (uint8, >= igemm_splitk_workspace_bytes), see
+    fp_igemm_f16_splitk_fwd.  Equal to igemm_f16 up to fp32 summation order."""
+    x = _dev(x, torch.float16, "x"); w = _dev(w, torch.float16, "w"); y = _dev(y, torch.float16, "y")
+    b = _dev(bias, torch.float32, "bias"); r = _dev(residual, torch.float16, "residual")
+    sc = _dev(bn_scale, torch.float32, "bn_scale"); sh = _dev(bn_shift, torch.float32, "bn_shift")
+    pe = _dev(pe, torch.float32, "pe"); y_pe = _dev(y_pe, torch.float16, "y_pe")
+    ws = _dev(workspace, torch.uint8, "workspace")
+    ep = IgemmEpilogue()
+    ep.bias, ep.bn_scale, ep.bn_shift = _ptr(b), _ptr(sc), _ptr(sh)
+    ep.residual = _ptr(r)
+    ep.r_geom = C.pointer(r_geom) if r_geom is not None else None
+    ep.flags = (IGEMM_RELU if relu else 0) | (IGEMM_ROUND_ACC if conv_rounding else 0)
+    ep.pe, ep.pe_period, ep.y_pe = _ptr(pe), (int(pe.shape[-2]) if pe is not None else 0), _ptr(y_pe)
+    st = _lib.lib().fp_igemm_f16_splitk_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(y), C.byref(y_geom), int(M), int(N), int(Cin),
+                                            int(taps), C.byref(ep), int(splits), _ptr(ws), ws.numel(), _stream(x))
+    _lib.check(st, "fp_igemm_f16_splitk_fwd")
+    return y
+
+
+def _work_igemm_splitk(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, splits, workspace, relu=False, residual=None, r_geom=None, **k):
+    return _work_igemm(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=relu, residual=residual, r_geom=r_geom)
+
+
 def _work_igemm(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None, **k):
     by = 2 * (M * Cin * (1 if taps == 1 else 1.0 / (x_geom.stride ** 2)) + N * Cin * taps + M * N * (2 if residual is not None else 1))
     return by, 2.0 * M * N * Cin * taps
@@ -612,6 +642,7 @@ crop_windows = _timed("fp_crop_windows", crop_windows)
 pose_update = _timed("fp_pose_update", pose_update)
 conv7x7s2_bn_relu = _timed("fp_conv7x7s2_bn_relu_fwd", conv7x7s2_bn_relu, _work_conv1)
 igemm_f16 = _timed("fp_igemm_f16_fwd", igemm_f16, _work_igemm)
+igemm_f16_splitk = _timed("fp_igemm_f16_splitk_fwd", igemm_f16_splitk, _work_igemm_splitk)
 add_pe_f16 = _timed("fp_add_pe_f16_fwd", add_pe_f16, lambda tok, pe: (4.0 * tok.numel(), 0.0))
 replicate_channels = _timed("fp_replicate_rows_f16", replicate_channels,
                             lambda buf, n, c0, c1: (2.0 * n * buf.shape[1] * buf.shape[2] * (c1 - c0), 0.0))

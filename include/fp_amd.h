@@ -59,8 +59,9 @@ const char* fp_last_error(void);
 /* ABI version of the library = FP_AMD_ABI_VERSION of the header it was built from; a binding compares the two at load time
  * (foundationpose_amd/_lib.py does and refuses a mismatch).  History of breaks that kept a symbol's name:
  *   200 -> 210 (round 4 / 5): fp_linear_layernorm_fwd takes the FRAGMENT-PACKED weight (fp_pack_linear512_f16) and requires K = 512;
- *                             a caller that still passes the nn.Linear-layout weight gets FP_OK and garbage -- check the version. */
-#define FP_AMD_ABI_VERSION 210
+ *                             a caller that still passes the nn.Linear-layout weight gets FP_OK and garbage -- check the version.
+ *   210 -> 211 (round 5): + fp_igemm_f16_splitk_fwd / fp_igemm_splitk_workspace_bytes (additions only). */
+#define FP_AMD_ABI_VERSION 211
 int fp_version(void);
 
 /* Utils.py:104-130 make_mesh_tensors: records caller-owned device tensors.
@@ -176,6 +177,19 @@ typedef struct {
 int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/, void* y /*dev*/,
                      const fp_igemm_geom* y_geom /*host*/, int M, int N, int Cin, int taps,
                      const fp_igemm_epilogue* epilogue /*host|NULL*/, void* stream);
+
+/* fp_igemm_f16_fwd for launches of a few dozen tiles -- the reference's tracking call (estimater.py:250-268: ONE hypothesis, so the
+ * 512 -> 512 convolutions are 400 x 512 x 4608 products = 16 tiles on 256 CUs, each running its whole k loop): the k range is cut into
+ * `splits` contiguous pieces of whole 64-wide k-steps, workgroup (tile, piece) leaves fp32 partial accumulators in `workspace`, and a
+ * second launch adds the pieces IN ORDER and applies the epilogue (same operations per element as fp_igemm_f16_fwd).  Deterministic;
+ * another fp32 summation order than fp_igemm_f16_fwd's, so equal to it up to summation order, not bit for bit -- a caller that
+ * needs the bits of a larger batch (shards, sub-batches) must not mix the two for one layer.  Arguments as fp_igemm_f16_fwd;
+ * 1 <= splits <= taps * Cin / 64; workspace: fp_igemm_splitk_workspace_bytes(M, N, splits) bytes of device scratch, 16-byte aligned. */
+size_t fp_igemm_splitk_workspace_bytes(int M, int N, int splits);
+int fp_igemm_f16_splitk_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/, void* y /*dev*/,
+                            const fp_igemm_geom* y_geom /*host*/, int M, int N, int Cin, int taps,
+                            const fp_igemm_epilogue* epilogue /*host|NULL*/, int splits, void* workspace /*dev*/,
+                            size_t workspace_bytes, void* stream);
 
 /* network_modules.py:133-137 PositionalEmbedding as the in_proj operand: out = f16(f32(tok) + pe[row % S]).
  * tok / out (M, D) fp16, pe (S, D) f32; D must be 512.  (The fp32 sum itself is never stored: fp_layernorm_res_fwd

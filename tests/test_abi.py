@@ -58,6 +58,14 @@ def test_argument_errors_are_reported_without_gpu():
     ep = IgemmEpilogue()
     ep.pe = 16                                          # positional table without its output / period
     assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, C.byref(ep), None) == -1
+    # split-K variant: workspace size, piece count and workspace checks come before any launch
+    assert lib.fp_igemm_splitk_workspace_bytes(400, 512, 12) == 12 * 4 * 4 * 65536 and lib.fp_igemm_splitk_workspace_bytes(400, 100, 2) == 0
+    assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, None, 0, C.c_void_p(16), 1 << 20, None) == -1
+    assert b"splits=0" in lib.fp_last_error()
+    assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, None, 9, C.c_void_p(16), 1 << 20, None) == -1
+    assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, None, 4, C.c_void_p(16), 1000, None) != 0
+    assert b"workspace" in lib.fp_last_error()
+    assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 0, 128, 512, 1, None, 4, None, 0, None) == 0   # nothing to do
     assert lib.fp_layernorm_res_fwd(None, C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,
                                     C.c_void_p(16), None, 4, 256, None) == -1
     assert lib.fp_layernorm_res_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1e-5,

@@ -139,6 +139,85 @@ def test_igemm_conv3x3_policy(dev, B, H, Cin, Cout, stride, res, bn):
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,res,bn,splits", [
+    (2, 40, 128, 128, 1, True, True, 6), (1, 40, 256, 256, 1, True, True, 6), (1, 20, 512, 512, 1, True, True, 12),
+    (2, 20, 512, 512, 1, False, False, 12), (2, 80, 64, 128, 2, False, True, 3), (1, 40, 256, 512, 2, False, True, 12),
+    (3, 20, 512, 512, 1, True, True, 72), (1, 8, 128, 128, 1, True, True, 1)])
+def test_igemm_splitk_policy(dev, B, H, Cin, Cout, stride, res, bn, splits):
+    """fp_igemm_f16_splitk_fwd (round 5: the convolutions of a one- or two-hypothesis call, i.e. the reference's track_one): the same
+    policy gate as fp_igemm_f16_fwd against the float64-accumulating emulation -- equal up to summation-order flips -- with the k range
+    in 1 .. 72 pieces (72 = one k-step per workgroup), ragged last row tiles, residual / BatchNorm / plain, and a poisoned workspace."""
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + H + splits)
+    x = F.relu(r16(torch.randn((B, Cin, H, H), generator=g) * 0.5))
+    w = r16(torch.randn((Cout, Cin, 3, 3), generator=g) * (1.0 / (3 * Cin ** 0.5)) + torch.arange(Cout)[:, None, None, None] * 1e-5)
+    bias = r16(torch.randn(Cout, generator=g) * 0.1)
+    sb = _bn(g, Cout) if bn else None
+    Ho = H // stride
+    r = r16(torch.randn((B, Cout, Ho, Ho), generator=g) * 0.5) if res else None
+    ref, mag, slack = conv_amp_ref(x, w, bias, sb, stride, residual=r)
+    xb = _padded_nhwc(x.half(), 1, dev)
+    wk = w.half().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dev)
+    rb = _padded_nhwc(r.half(), 1, dev) if res else None
+    gin = ops.IgemmGeom.image(Ho, Ho, 1, Cin, stride=stride, offset=0)
+    gin.padded_h, gin.padded_w = H + 2, H + 2
+    gout = ops.IgemmGeom.image(Ho, Ho, 1, Cout)
+    M = B * Ho * Ho
+    need = ops.igemm_splitk_workspace_bytes(M, Cout, splits)
+    assert need == splits * (-(-M // 128)) * (Cout // 128) * 65536
+    outs = []
+    for fill in (0x7f, 0xff):                      # NaN patterns in the scratch: every word that is read has been written
+        ws = torch.full((need + 64,), fill, dtype=torch.uint8, device=dev)
+        y = torch.zeros((B, Ho + 2, Ho + 2, Cout), dtype=torch.float16, device=dev)
+        ops.igemm_f16_splitk(xb, gin, wk, bias.to(dev), y, gout, M, Cout, Cin, 9, splits, ws[:need], relu=True, residual=rb,
+                             r_geom=gout if res else None, bn_scale=sb[0].to(dev) if bn else None, bn_shift=sb[1].to(dev) if bn else None,
+                             conv_rounding=True)
+        assert bool((ws[need:] == fill).all()), "wrote past the workspace"
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])           # deterministic, independent of what the scratch held
+    y = outs[0]
+    out = y[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).float().cpu()
+    cap = (2.0 + (2.2 if bn else 0.0)) + (1.0 if res else 0.0)
+    rep = assert_equal_up_to_flips(out.numpy(), ref.numpy(), mag.numpy(), max_frac=0.03, max_ulps=cap, what="conv3x3 split-K", slack=slack.numpy())
+    REPORT.setdefault("kernel_flip_rates", {})[f"conv3x3 split-K x{splits} B{B} H{H} {Cin}->{Cout} s{stride}"] = rep
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0 and float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+    # against the unsplit entry point: the same values up to flips of the final rounding (another fp32 order), nothing else
+    y0 = torch.zeros_like(y)
+    ops.igemm_f16(xb, gin, wk, bias.to(dev), y0, gout, M, Cout, Cin, 9, relu=True, residual=rb, r_geom=gout if res else None,
+                  bn_scale=sb[0].to(dev) if bn else None, bn_shift=sb[1].to(dev) if bn else None, conv_rounding=True)
+    differing = float((y0 != y).float().mean())
+    assert differing <= 0.03, differing
+    # too small a workspace / a piece count beyond the k-steps are refused
+    import foundationpose_amd._lib as L
+    with pytest.raises(L.FpAmdError):
+        ops.igemm_f16_splitk(xb, gin, wk, bias.to(dev), y, gout, M, Cout, Cin, 9, splits, ws[:need - 16], conv_rounding=True)
+    with pytest.raises(L.FpAmdError):
+        ops.igemm_f16_splitk(xb, gin, wk, bias.to(dev), y, gout, M, Cout, Cin, 9, 9 * Cin // 64 + 1, ws, conv_rounding=True)
+
+
+def test_splitk_linear_with_positional_output(dev):
+    """taps = 1 (nn.Linear rounding) and the fused positional second output through the split-K path, ragged M"""
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for M, K, N, relu, splits in ((400, 512, 512, True, 8), (37, 64, 128, False, 1), (801, 512, 1536, False, 4)):
+        xm = r16(torch.randn((M, K), generator=g))
+        wm = r16(torch.randn((N, K), generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-4)
+        b = r16(torch.randn(N, generator=g))
+        acc = (xm.double() @ wm.double().t() + b.double()).float()
+        slack = (1e-6 * (xm.double().abs() @ wm.double().abs().t())).float()
+        refm = r16(acc)
+        refm = F.relu(refm) if relu else refm
+        ym = torch.empty((M, N), dtype=torch.float16, device=dev)
+        pe = torch.randn((100, N), generator=g)
+        ype = torch.empty((M, N), dtype=torch.float16, device=dev)
+        ws = torch.empty(ops.igemm_splitk_workspace_bytes(M, N, splits), dtype=torch.uint8, device=dev)
+        ops.igemm_f16_splitk(xm.half().to(dev), ops.IgemmGeom.matrix(K), wm.half().to(dev), b.to(dev), ym, ops.IgemmGeom.matrix(N), M, N, K, 1,
+                             splits, ws, relu=relu, pe=pe.to(dev), y_pe=ype)
+        assert torch.equal(ype.cpu(), (ym.float().cpu() + pe[torch.arange(M) % 100]).half()), "fused positional table"
+        assert_equal_up_to_flips(ym.float().cpu().numpy(), refm.numpy(), acc.abs().numpy(), max_frac=0.02, what=f"split-K linear {M}x{K}x{N}",
+                                 slack=slack.numpy())
+
+
 def test_igemm_channel_concat_and_linear_policy(dev):
     """bsplit writes image b and image b+n side by side along C (the A|B feature concat); taps=1 is nn.Linear (one
     rounding of accumulator + bias), with ragged last tiles and ReLU"""
