@@ -202,6 +202,7 @@ def _conv_params(sd, conv_p, bn_p):
 # 4, 1.93 -> 1.39 at 8, 2.02 -> 1.71 at 12, 2.05 -> 1.96 at 16, slower from 24 on.  Must stay below the sub-batch minimum (overlap.SubBatches
 # min_rows = 32): a call that is split into sub-batches never takes this path, so the parts of a call and the whole call always agree.
 SPLITK_MAX_HYPS = int(__import__("os").environ.get("FP_AMD_SPLITK_MAX_HYPS", "12"))
+HEADS_TWO_STREAMS_MAX_HYPS = int(__import__("os").environ.get("FP_AMD_HEADS_TWO_STREAMS_MAX_HYPS", "12"))   # RefinePlan: see __call__
 SPLITK_TARGET_WGS = 384        # (tile, piece) workgroups a launch should have: 1.5 per CU
 
 
@@ -420,6 +421,18 @@ class RefinePlan:
                 self.heads[name] = (_TorchEncoderLayer(sd, f"{name}_head.0", self.dtype),
                                     sd[f"{name}_head.1.weight"].to(self.dtype), sd[f"{name}_head.1.bias"].to(self.dtype))
 
+    def _head_side_stream(self, tok16):
+        """the side stream the rotation head of a SMALL call runs on, or None: calls of more than HEADS_TWO_STREAMS_MAX_HYPS
+        hypotheses fill the chip by themselves (and the side stream belongs to their sub-batches), a per-kernel timing pass wants
+        one stream, and a side stream that shares the main stream's hardware queue buys nothing"""
+        if not getattr(self, "two_stream_heads", True) or tok16.shape[0] > HEADS_TWO_STREAMS_MAX_HYPS or tok16.device.type != "cuda" \
+                or ops.KernelTimers.active is not None:
+            return None
+        from . import overlap
+        if not overlap.side_streams_overlap(tok16.device, 1):
+            return None
+        return overlap.reserve_streams(tok16.device, 1)[0]
+
     @torch.inference_mode()
     def __call__(self, AB, slot=0, shared_b=False):
         """AB (2N,6,H,W) in the plan's dtype -> {'trans': (N,3) f32, 'rot': (N,3|6) f32}.  slot: activation-buffer set
@@ -435,10 +448,26 @@ class RefinePlan:
             return {k: v.float() for k, v in o.items()}                 # predict_pose_refine.py:192-193
         if self.hip:
             tok16, x16 = self.enc(AB, slot, shared_b=shared_b)
-            for name, (layer, head) in self.heads.items():
-                # Linear and the token mean commute: mean_t(x_t W^T + b) = (mean_t x_t) W^T + b, so the 512 -> 3|6 head
-                # runs on N rows instead of N*400 (refine_network.py:90-91); the result is held in fp16 by the reference
-                out[name] = head(layer.pooled(tok16, x16, self.enc.pe), round_f16=True)
+            # Linear and the token mean commute: mean_t(x_t W^T + b) = (mean_t x_t) W^T + b, so the 512 -> 3|6 head
+            # runs on N rows instead of N*400 (refine_network.py:90-91); the result is held in fp16 by the reference
+            run = lambda name: self.heads[name][1](self.heads[name][0].pooled(tok16, x16, self.enc.pe), round_f16=True)
+            side = self._head_side_stream(tok16)
+            if side is None:
+                for name in self.heads:
+                    out[name] = run(name)
+                return out
+            # round 5: a call of a few hypotheses (the reference's track_one: ONE) is a chain of ~100 latency-bound launches on an
+            # empty chip, and the two heads are independent given the tokens (refine_network.py:90-91): the rotation head runs on the
+            # process's side stream beside the translation head -- the same kernels on the same data, so the same bits; fork / join are
+            # stream waits, i.e. parallel branches under hipGraph capture (as for the sub-batches of overlap.py)
+            cur = torch.cuda.current_stream(tok16.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                out["rot"] = run("rot")
+            out["trans"] = run("trans")
+            cur.wait_stream(side)
+            for t in (tok16, x16, out["rot"]):
+                t.record_stream(side)
             return out
         with _conv_backend():
             tok = self.enc(AB)

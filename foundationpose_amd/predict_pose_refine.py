@@ -168,6 +168,7 @@ class PoseRefinePredictor:
         dev = next(self.model.parameters()).device
         if self._plan is None or self._plan_dev != dev:
             self._plan = RefinePlan(self.model, dev, **self._plan_opts)
+            self._plan.two_stream_heads = self.sub.n_streams > 1      # n_streams=1 switches every use of the side stream off
             self._plan_dev = dev
         return self._plan
 

@@ -1355,3 +1355,40 @@ def test_captured_renders_without_a_workspace_do_not_share_scratch(scene, dev, g
         torch.cuda.synchronize()
         bad += int(any(not torch.equal(sets[i][2], base[i]) for i in range(2)))
     assert bad == 0, f"{bad} of 60 concurrent replays differ from the eager launches"
+
+
+@pytest.mark.parametrize("n", [1, 3, 12])
+def test_small_calls_two_stream_heads_and_splitk_change_nothing_but_the_summation_order(scene, dev, gmesh, frame, n):
+    """Round 5, the small-call path (the reference's track_one is ONE hypothesis): (i) the rotation head on the side stream beside
+    the translation head returns the bits of the one-stream launch order, eagerly and as a captured graph; (ii) split-K convolutions
+    change the fp32 summation order only: one teacher-forced iteration stays within the fp16 policy's noise of the plain kernels."""
+    from foundationpose_amd import engine
+    from foundationpose_amd.graphs import GraphedTracker
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import CONTRACTION_HEAD_SCALE, DEFAULT_REFINE_CFG, random_state_dict
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = random_state_dict("refine", cfg, seed=0, head_scale=CONTRACTION_HEAD_SCALE)
+    P0 = torch.as_tensor(scene["poses"][[3, 77, 140, 201, 250, 17, 33, 90, 111, 160, 222, 5][:n]], device=dev)
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    saved = engine.HEADS_TWO_STREAMS_MAX_HYPS, engine.SPLITK_MAX_HYPS
+    outs = {}
+    try:
+        for name, heads, sk in (("product", 12, 12), ("one_stream", 0, 12), ("plain_convs", 12, 0)):
+            engine.HEADS_TWO_STREAMS_MAX_HYPS, engine.SPLITK_MAX_HYPS = heads, sk
+            pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16", graph=False)
+            o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], iteration=2, **kw)
+            outs[name] = o.clone()
+            if name == "product":
+                raw = {k: v.clone() for k, v in pred.last_raw_output.items()}
+                trk = GraphedTracker(pred, gmesh, scene["diameter"], scene["K"], 480, 640, n_hyp=n, iteration=2, device=dev).capture()
+                g1 = trk.step(scene["rgb"], scene["depth"], P0).clone()
+                e1 = trk.step_eager(scene["rgb"], scene["depth"], P0).clone()
+                assert torch.equal(g1, e1), "graph replay of the forked heads differs from the eager launches"
+    finally:
+        engine.HEADS_TWO_STREAMS_MAX_HYPS, engine.SPLITK_MAX_HYPS = saved
+    assert torch.equal(outs["product"], outs["one_stream"]), "two-stream heads changed a result"
+    assert set(raw) == {"trans", "rot"}
+    # split-K against the plain convolutions: contraction-scaled heads, so the 2-iteration chain compares arithmetic, not chaos
+    dR = _geodesic(outs["product"][:, :3, :3].cpu().numpy(), outs["plain_convs"][:, :3, :3].cpu().numpy())
+    dt = np.linalg.norm((outs["product"][:, :3, 3] - outs["plain_convs"][:, :3, 3]).cpu().numpy(), axis=1)
+    assert dR.max() <= 1e-4 and dt.max() <= 1e-5, (dR.max(), dt.max())      # measured 2.2e-5 rad / 5.1e-6 m over two free-running iterations
