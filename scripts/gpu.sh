@@ -9,7 +9,7 @@ mkdir -p $O
 T0=$(date +%s)
 el() { echo "== $1 (t=$(( $(date +%s) - T0 )) s)"; }
 CS=foundationpose_amd/csrc
-BENCH_FAST="--no-cpu-baseline --no-kernel-table"
+BENCH_FAST="--no-cpu-baseline --no-kernel-table --no-extras"
 
 t_sane() {
   timeout 200 python -c "import torch; x = torch.ones(1 << 22, device='cuda'); assert (x * 2).sum().item() == 2 * (1 << 22); print('gpu sane')" || { echo "GPU NOT SANE"; exit 7; }
