@@ -60,3 +60,53 @@ def test_yardstick_reproduces_here_and_fp32_oracle_is_close(scene, G):
         # fp32 accumulation: a few fp16 ulps of the raw output away from the exactly-rounded one, never far
         d32 = np.abs(o32[k].numpy() - g)
         assert d32.max() <= 16 * ulp16(np.abs(g).max()), (k, d32.max())
+
+
+def test_fitted_heads_golden_reproduces_here_and_refines(scene):
+    """round 5: tests/golden/acc64_fitted_chain_golden.npz (make_golden_acc64_fitted.py; the stand-in refiner with heads fitted by
+    tests/golden/fit_contraction_heads.py) -- the starts are the seeded perturbations, the first iteration's exactly-rounded pose is what
+    this machine computes for a few hypotheses, the stand-in REFINES (error to the ground truth shrinks), and the golden's own
+    fp32-accumulating oracle chain documents the amplification of a free-running chain (the reason its 1e-4 gate stays with the
+    contraction-scaled heads)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_acc64_fitted import start_poses
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    from oracle import nets_amp, ops as oo
+    from oracle import pipeline as op
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "acc64_fitted_chain_golden.npz")))
+    P0 = start_poses(scene["gt"])
+    assert np.array_equal(P0, g["start"]) and np.array_equal(g["chain"][0], P0) and np.array_equal(g["oracle_chain"][0], P0)
+    assert g["chain"].shape == (6, 252, 4, 4) and np.isfinite(g["chain"]).all()
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = random_state_dict("refine", cfg, seed=0, heads="fitted")
+    ref = random_state_dict("refine", cfg, seed=0)
+    for k in sd:                                           # only the two output heads differ from the calibrated seed-0 checkpoint
+        same = torch.equal(sd[k], ref[k])
+        assert same != k.startswith(("trans_head.1.", "rot_head.1.")), k
+    assert float(sd["rot_head.1.weight"].norm()) < 0.5 * float(ref["rot_head.1.weight"].norm())
+    d = op.preprocess_depth(scene["depth"])
+    xyz = oo.depth2xyzmap(d, scene["K"], f64_internal=True)
+    A, B, _, _ = op.refine_inputs(cfg, P0, scene["mesh_np"], scene["rgb"], xyz, scene["K"], scene["diameter"])
+    assert (_crc(A), _crc(B)) == tuple(int(v) for v in g["crc"][0])
+    n = 4
+    nets_amp.ACC64 = True
+    try:
+        o = nets_amp.refine_forward(torch.from_numpy(A[:n]), torch.from_numpy(B[:n]), sd)
+    finally:
+        nets_amp.ACC64 = False
+    tn = [float(v) for v in cfg["trans_normalizer"]]
+    new = oo.pose_update(o["trans"].numpy(), o["rot"].numpy(), P0[:n], cfg["rot_rep"], bool(cfg["normalize_xyz"]), tn, float(cfg["rot_normalizer"]),
+                         float(scene["diameter"]))
+    assert np.abs(new - g["chain"][1][:n]).max() <= 1e-6          # exactly rounded = reproducible (up to libm ulps in the pose update)
+    # it refines: one iteration brings the translation error to the ground truth under half, the rotation error down
+    G = np.tile(scene["gt"][None], (252, 1, 1))
+    e = lambda P: (geodesic(P[:, :3, :3], G[:, :3, :3]), np.linalg.norm(P[:, :3, 3] - G[:, :3, 3], axis=1))
+    e0, e1 = e(g["chain"][0]), e(g["chain"][1])
+    assert np.median(e1[1]) < 0.5 * np.median(e0[1]) and np.median(e1[0]) < 0.9 * np.median(e0[0])
+    upd = geodesic(g["chain"][1][:, :3, :3], g["chain"][0][:, :3, :3])
+    assert np.median(upd) > 0.04                                   # full-size, directed updates
+    # one iteration: the fp32-accumulating oracle is at the fp16 policy's noise floor; free running it leaves the exact chain
+    d1 = geodesic(g["oracle_chain"][1][:, :3, :3], g["chain"][1][:, :3, :3])
+    d5 = geodesic(g["oracle_chain"][5][:, :3, :3], g["chain"][5][:, :3, :3])
+    assert np.median(d1) < 6e-4 and np.median(d5) > 20 * np.median(d1)
