@@ -201,8 +201,8 @@ def _conv_params(sd, conv_p, bn_p):
 # measured (scripts/bench_small_batches.py, profiles/r05_k_small_batches.log): predict(n, 2 iterations) 1.90 -> 1.05 ms at n = 1, 1.90 -> 1.21 at
 # 4, 1.93 -> 1.39 at 8, 2.02 -> 1.71 at 12, 2.05 -> 1.96 at 16, slower from 24 on.  Must stay below the sub-batch minimum (overlap.SubBatches
 # min_rows = 32): a call that is split into sub-batches never takes this path, so the parts of a call and the whole call always agree.
-SPLITK_MAX_HYPS = int(__import__("os").environ.get("FP_AMD_SPLITK_MAX_HYPS", "12"))
-HEADS_TWO_STREAMS_MAX_HYPS = int(__import__("os").environ.get("FP_AMD_HEADS_TWO_STREAMS_MAX_HYPS", "12"))   # RefinePlan: see __call__
+SPLITK_MAX_HYPS = int(os.environ.get("FP_AMD_SPLITK_MAX_HYPS", "12"))
+HEADS_TWO_STREAMS_MAX_HYPS = int(os.environ.get("FP_AMD_HEADS_TWO_STREAMS_MAX_HYPS", "12"))   # RefinePlan: see __call__
 SPLITK_TARGET_WGS = 384        # (tile, piece) workgroups a launch should have: 1.5 per CU
 
 
