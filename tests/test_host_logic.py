@@ -109,3 +109,31 @@ def test_fragment_packed_weight_layout_is_what_the_mfma_operand_needs():
         assert np.array_equal(rows, 64 * w + 32 * i + np.arange(32)) and np.array_equal(cols, 16 * q + np.arange(16))
         lane = 37                                                                        # lane 37 = row 5, upper k half
         assert np.array_equal(blk[lane * 8:lane * 8 + 8], W[64 * w + 32 * i + 5, 16 * q + 8:16 * q + 16])
+
+
+def test_small_call_thresholds_keep_the_equalities_of_the_library():
+    """round 5, engine.SPLITK_MAX_HYPS / HEADS_TWO_STREAMS_MAX_HYPS / splitk_pieces (no GPU): the small-call path is chosen by the
+    hypothesis count of a CALL, and a call that is split into sub-batches must never take it -- otherwise the parts of a call and the
+    whole call would disagree on the summation order.  Pieces: at least two k-steps each, never more than the k-steps
+    allow, enough (tile, piece) workgroups to fill the chip at one hypothesis, and the same for the shared-observed-crop stem as for
+    the plain stem (both pass the plain form's row count)."""
+    from foundationpose_amd import engine
+    from foundationpose_amd.overlap import SubBatches
+    sub = SubBatches(2)
+    assert engine.SPLITK_MAX_HYPS < sub.min_rows and engine.HEADS_TWO_STREAMS_MAX_HYPS < sub.min_rows
+    for n in range(1, 2 * sub.min_rows):
+        assert len(sub.parts(n)) == 1                      # below 2 x min_rows a call is one part: n of the part = n of the call
+    assert all(b - a >= sub.min_rows for a, b in sub.parts(2 * sub.min_rows))
+    layers = lambda n: ((2 * n * 1600, 128, 64), (2 * n * 1600, 128, 128), (n * 1600, 256, 256), (n * 400, 512, 256), (n * 400, 512, 512))
+    for n in range(1, engine.SPLITK_MAX_HYPS + 1):
+        for rows, cout, cin in layers(n):
+            nk = 9 * cin // 64
+            p = engine.splitk_pieces(rows, cout, cin)
+            assert 1 <= p <= max(1, nk // 2)
+            tiles = -(-rows // 128) * (cout // 128)
+            if n == 1 and nk >= 18:
+                assert tiles * p >= 128                    # one hypothesis: at least half a workgroup per CU instead of 7-26 tiles
+    # monotone: more hypotheses never means more pieces
+    for rows, cout, cin in layers(1):
+        ps = [engine.splitk_pieces(rows * n, cout, cin) for n in range(1, 13)]
+        assert all(a >= b for a, b in zip(ps, ps[1:])), ps
