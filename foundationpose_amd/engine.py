@@ -342,18 +342,33 @@ class _HipRowsLinear:
 
 
 class _HipMHA:
-    def __init__(self, sd, p, fp16_scores, nhead=4):
+    def __init__(self, sd, p, fp16_scores, nhead=4, small_calls=True):
         self.qkv = _HipLinear(sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"])
         self.out = _HipLinear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
         self.out_rows = _HipRowsLinear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
         self.nhead, self.fp16_scores = nhead, fp16_scores
         self.qkv_p = ops.PackedLinear512(self.qkv.w) if tuple(self.qkv.w.shape) == (1536, 512) else None
+        # small calls: the in_proj of a call of <= SPLITK_MAX_HYPS sequences is a 48-tile launch of 8 k-steps each; split
+        # in four it fills the chip.  Not for the scorer's cross-hypothesis attention (one "sequence" of N hypotheses: its row count is
+        # the hypothesis count of the call, and every rank of a sharded call has to see the same arithmetic there).
+        self.small_calls = small_calls
+        self._sk = {}
 
     def context(self, x16):
         """softmax(q k^T / sqrt(d)) v with heads merged, before the output projection: (Bn, L, D) fp16"""
         Bn, L, D = x16.shape
         if ROWS_QKV and self.qkv_p is not None and Bn * L >= ROWS_QKV_MIN_ROWS:
             qkv = ops.linear512(x16, self.qkv_p, self.qkv.b)
+        elif self.small_calls and Bn <= SPLITK_MAX_HYPS and D % 64 == 0 and D // 64 >= 4:
+            M, No = Bn * L, self.qkv.w.shape[0]
+            pieces = max(1, min(D // 64 // 2, round(SPLITK_TARGET_WGS / (-(-M // 128) * (No // 128)))))
+            key = (M, No, pieces, x16.device)
+            ws = self._sk.get(key)
+            if ws is None:
+                ws = self._sk[key] = torch.empty(ops.igemm_splitk_workspace_bytes(M, No, pieces), dtype=torch.uint8, device=x16.device)
+            qkv = torch.empty((M, No), dtype=torch.float16, device=x16.device)
+            Gm = ops.IgemmGeom.matrix
+            ops.igemm_f16_splitk(x16.reshape(M, D), Gm(D), self.qkv.w, self.qkv.b, qkv, Gm(No), M, No, D, 1, pieces, ws)
         else:
             qkv = self.qkv(x16)
         return ops.attention_f16(qkv.reshape(Bn, L, 3 * D), self.nhead, fp16_scores=self.fp16_scores)
@@ -488,7 +503,7 @@ class ScorePlan:
         if self.hip:
             self.enc = _HipEncoder(sd, "encoderA", "encoderAB", device)
             self.att = _HipMHA(sd, "att", fp16_scores=True)
-            self.att_cross = _HipMHA(sd, "att_cross", fp16_scores=True)
+            self.att_cross = _HipMHA(sd, "att_cross", fp16_scores=True, small_calls=False)
             self.lin = _HipRowsLinear(sd["linear.weight"], sd["linear.bias"])
         else:
             self.enc = _Encoder(sd, "encoderA", "encoderAB", self.dtype, channels_last)
