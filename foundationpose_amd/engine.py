@@ -197,7 +197,8 @@ def _conv_params(sd, conv_p, bn_p):
 # launches of 16-26 tiles on 256 CUs, each tile running its whole k loop (55 us per launch on average, 73 % of track_one's GPU time);
 # fp_igemm_f16_splitk_fwd cuts the k range instead.  The decision depends on the HYPOTHESIS COUNT of the call only (not on the image
 # count of a launch: the shared-observed-crop form of the stem must keep the summation order of the plain form) and the number of
-# pieces is a constant of the layer, so sub-batches, the two-pose quirk and graph replays of one call all see the same arithmetic.
+# pieces is a function of the layer and of that count (splitk_pieces), so the two-pose quirk, the shared-crop stem and graph replays
+# of one call all see the same arithmetic; calls that are split into sub-batches never come here (see below).
 # measured (scripts/bench_small_batches.py, profiles/r05_k_small_batches.log): predict(n, 2 iterations) 1.90 -> 1.05 ms at n = 1, 1.90 -> 1.21 at
 # 4, 1.93 -> 1.39 at 8, 2.02 -> 1.71 at 12, 2.05 -> 1.96 at 16, slower from 24 on.  Must stay below the sub-batch minimum (overlap.SubBatches
 # min_rows = 32): a call that is split into sub-batches never takes this path, so the parts of a call and the whole call always agree.
