@@ -14,7 +14,8 @@ import json
 import re
 import sys
 
-FAMILIES = [("gemm", r"k_conv_sw|k_igemm"), ("attention", r"k_attention"), ("patch_embed", r"k_conv7x7"), ("rowops", r"k_layernorm|k_colmean|k_rows_linear|k_add_pe"),
+FAMILIES = [("gemm", r"k_conv_sw|k_igemm|k_rows512|k_linear512|k_splitk"),      # round 4/5: the row-owning projection kernels and the split-K pair belong to the GEMM arithmetic
+             ("attention", r"k_attention"), ("patch_embed", r"k_conv7x7"), ("rowops", r"k_layernorm|k_colmean|k_rows_linear|k_add_pe|k_ln_mean_finish"),
             ("raster", r"k_raster|k_bin|k_vertex"), ("warp", r"k_warp"), ("pose", r"k_crop_windows|k_pose_update")]
 MFMA_PEAK = 2500.0
 # GEMM-family arithmetic per hypothesis-pass (SURVEY 8(d), 2 x MAC): 15 3x3 convs + the 512-wide projections of the heads;
