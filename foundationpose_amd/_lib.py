@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime with PyTo
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FP_AMD_LIB") or os.path.join(_HERE, "csrc", "libfp_amd.so")   # FP_AMD_LIB: A/B builds
-ABI_VERSION = 211    # = FP_AMD_ABI_VERSION of include/fp_amd.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 212    # = FP_AMD_ABI_VERSION of include/fp_amd.h (tests/test_abi.py keeps the two in step)
 _lib = None
 
 vp, ci, cf, cd, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
@@ -31,6 +31,7 @@ SIGNATURES = {
     "fp_pose_update": (ci, [vp, vp, vp, ci, ci, vp, cf, cf, ci, vp, vp, vp, ci, vp, vp, cf, vp]),
     "fp_conv7x7s2_bn_relu_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "fp_igemm_f16_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "fp_pack_conv3x3_tiles_f16": (ci, [vp, vp, ci, ci, vp]),
     "fp_igemm_splitk_workspace_bytes": (sz, [ci, ci, ci]),
     "fp_igemm_f16_splitk_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, ci, vp, sz, vp]),
     "fp_add_pe_f16_fwd": (ci, [vp, vp, vp, ci, ci, ci, vp]),

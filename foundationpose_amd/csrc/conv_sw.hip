@@ -127,8 +127,16 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
     const int c = (lane & 3) ^ swz(row);
     woff32[j] = (unsigned)((((size_t)(n0 + row) * Ktot) + c * 8) * 2);
   }
+  // Tile-packed weights (round 5, fp_pack_conv3x3_tiles_f16; BN = 128 only): the 8 KiB a k-step stages are one contiguous run that
+  // already is the LDS image, so a piece is 1 KiB of consecutive addresses (8 whole 128-byte lines) instead of 16 half lines of 16 weight rows
+  const bool wpk = (BN == 128) && p.Wpk != nullptr;
+  if (wpk) {
+#pragma unroll
+    for (int j = 0; j < WI; ++j) woff32[j] = (unsigned)(((wid * WI + j) * 64 + lane) * 16);
+  }
+  const int wpk_base = wpk ? bn * (ncc * 9) * W_BYTES : 0;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Wt), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(wpk ? p.Wpk : p.Wt), 0, 0x7FFFFFFF, 0x00020000);
 
   auto stage_patch = [&](int cc, int j) {          // piece j (0..3) of this wave of the patch of chunk cc
     unsigned char* dst = patch + (cc & 1) * SW_PATCH_BYTES + (wid * PI + j) * 1024;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
                                              cc * (BK * 2), 0, 0);
   };
   auto stage_w = [&](int cc, int tap, int slot) {  // weight columns [tap*Cin + cc*32, +32) of the tile's BN rows
-    const int wsoff = (tap * Cin + cc * BK) * 2;
+    const int wsoff = wpk ? wpk_base + (cc * 9 + tap) * W_BYTES : (tap * Cin + cc * BK) * 2;
     unsigned char* dst = wring + slot * W_BYTES + wid * (WI * 1024);
 #pragma unroll
     for (int j = 0; j < WI; ++j)
@@ -528,4 +536,32 @@ int fp_conv3x3_sw_launch(const IgemmParams& p, hipStream_t stream) {
   if (sw_variant(p) == 1) return sw_ls_launch<256, 128, 4>(p, stream);
   if (sw_use_256(p)) return sw_launch<256, 256, 4>(p, stream);
   return sw_launch<512, 128, 4>(p, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp_pack_conv3x3_tiles_f16: one thread per 16-byte chunk of the packed matrix (include/fp_amd.h has the layout)
+__global__ __launch_bounds__(256) void k_pack_conv3x3_tiles(const _Float16* __restrict__ w, _Float16* __restrict__ out, int N, int Cin) {
+  const int nk = 9 * (Cin / 32);
+  const long long total = (long long)N * nk * 4;          // chunks: N rows x nk k-steps x 4 chunks of 8 halves
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= total) return;
+  const int pc = (int)(q & 3);
+  const int r = (int)((q >> 2) & 127);
+  const long long blk = q >> 9;                            // bn * nk + s
+  const int s = (int)(blk % nk), bn = (int)(blk / nk);
+  const int cc = s / 9, tap = s - 9 * cc;
+  const int lc = pc ^ ((r >> 2) & 3);
+  const half8 v = *reinterpret_cast<const half8*>(w + (size_t)(bn * 128 + r) * (9 * Cin) + tap * Cin + cc * 32 + lc * 8);
+  *reinterpret_cast<half8*>(out + q * 8) = v;
+}
+
+extern "C" int fp_pack_conv3x3_tiles_f16(const void* w, void* w_tiles, int N, int Cin, void* stream) {
+  FP_REQUIRE(w && w_tiles && w != w_tiles, "fp_pack_conv3x3_tiles_f16: NULL tensor or in-place repack");
+  FP_REQUIRE(N > 0 && N % 128 == 0 && Cin > 0 && Cin % 32 == 0, "fp_pack_conv3x3_tiles_f16: N=%d must be a multiple of 128, Cin=%d of 32", N, Cin);
+  FP_REQUIRE((((size_t)w | (size_t)w_tiles) & 15) == 0, "fp_pack_conv3x3_tiles_f16: tensors must be 16-byte aligned");
+  const long long total = (long long)N * 9 * (Cin / 32) * 4;
+  hipLaunchKernelGGL(k_pack_conv3x3_tiles, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w,
+                     (_Float16*)w_tiles, N, Cin);
+  FP_CHECK_LAUNCH("fp_pack_conv3x3_tiles_f16");
+  return FP_OK;
 }

@@ -390,7 +390,7 @@ static int ig_build_params(const void* x, const fp_igemm_geom* x_geom, const voi
   FP_REQUIRE(taps == 1 || taps == 9, "fp_igemm_f16_fwd: taps must be 1 (GEMM) or 9 (3x3 conv), got %d", taps);
   FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
   FP_REQUIRE(Cin > 0 && Cin % 64 == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of 64", Cin);
-  static const fp_igemm_epilogue no_epilogue = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr};
+  static const fp_igemm_epilogue no_epilogue = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr};
   const fp_igemm_epilogue& e = ep ? *ep : no_epilogue;
   FP_REQUIRE(!e.residual || e.r_geom, "fp_igemm_f16_fwd: residual without geometry");
   FP_REQUIRE((e.bn_scale == nullptr) == (e.bn_shift == nullptr), "fp_igemm_f16_fwd: bn_scale and bn_shift go together");
@@ -402,7 +402,8 @@ static int ig_build_params(const void* x, const fp_igemm_geom* x_geom, const voi
   if (int err = ig_check_geom(x_geom, "input")) return err;
   if (int err = ig_check_geom(y_geom, "output")) return err;
   if (e.residual) if (int err = ig_check_geom(e.r_geom, "residual")) return err;
-  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.bias = e.bias; p.bn_scale = e.bn_scale; p.bn_shift = e.bn_shift;
+  FP_REQUIRE(!e.w_tiles || (taps == 9 && (((size_t)e.w_tiles) & 15) == 0 && e.w_tiles != w), "fp_igemm_f16_fwd: w_tiles is for 3x3 convolutions, 16-byte aligned, not w itself");
+  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.Wpk = (const _Float16*)e.w_tiles; p.bias = e.bias; p.bn_scale = e.bn_scale; p.bn_shift = e.bn_shift;
   p.R = (const _Float16*)e.residual; p.Y = (_Float16*)y;
   p.pe = e.pe; p.Ype = (_Float16*)e.y_pe; p.pe_period = e.pe_period;
   p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = (e.flags & FP_IGEMM_RELU) ? 1 : 0;

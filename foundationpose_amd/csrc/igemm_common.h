@@ -40,6 +40,7 @@ __device__ __forceinline__ int ig_fastdiv(int n, unsigned mul, unsigned shr) {
 struct IgemmParams {
   const _Float16* A;
   const _Float16* Wt;   // [N][taps*Cin]
+  const _Float16* Wpk;  // the same weights tile-packed (fp_pack_conv3x3_tiles_f16) or null: read by k_conv_sw<512,128> only
   const float* bias;    // [N] or null
   const float* bn_scale;   // [N] or null: eval-mode BatchNorm as y = x * scale + shift, applied to the fp16-rounded conv + bias
   const float* bn_shift;

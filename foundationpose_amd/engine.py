@@ -69,6 +69,9 @@ FUSED_FFN = os.environ.get("FP_AMD_FUSED_FFN", "1") != "0"
 # launches below ROWS_QKV_MIN_ROWS rows (the scorer's cross-hypothesis attention: 252 rows) stay there as well.
 ROWS_QKV = os.environ.get("FP_AMD_ROWS_QKV", "1") != "0"
 ROWS_QKV_MIN_ROWS = 4096
+# round 5: the encoder's stride-1 3x3 convolutions hand fp_igemm_f16_fwd a tile-packed copy of their weights as well (epilogue.w_tiles): the
+# shifted-window kernel then stages a k-step's weight tile from one contiguous 8 KiB run.  Same operands, same order: the same bits.
+PACKED_CONV_TILES = os.environ.get("FP_AMD_PACKED_CONV_TILES", "1") != "0"
 
 
 def _conv_backend():
@@ -189,8 +192,12 @@ def _conv_params(sd, conv_p, bn_p):
     w = sd[conv_p + ".weight"].float()
     b = sd.get(conv_p + ".bias")
     scale, shift = _bn_affine(sd, bn_p)
-    return dict(w=w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.float16).contiguous(),
-                bias=None if b is None else _r16(b.float()), scale=scale, shift=shift)
+    wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.float16).contiguous()
+    # round 5: the tile-packed copy the shifted-window kernel fetches as contiguous 8 KiB runs (fp_pack_conv3x3_tiles_f16); 3x3 only
+    tiles = None
+    if wk.is_cuda and w.shape[2] == 3 and w.shape[3] == 3 and w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0 and PACKED_CONV_TILES:
+        tiles = ops.pack_conv3x3_tiles(wk, w.shape[0], w.shape[1])
+    return dict(w=wk, w_tiles=tiles, bias=None if b is None else _r16(b.float()), scale=scale, shift=shift)
 
 
 # Round 5: split-K for the reference's tracking call.  With ONE hypothesis (estimater.py:250-268) the encoder's convolutions are
@@ -274,7 +281,8 @@ class _HipEncoder:
                                         relu=relu, residual=res, r_geom=gres, bn_scale=c["scale"], bn_shift=c["shift"],
                                         conv_rounding=True, pe=pe, y_pe=y_pe)
         return ops.igemm_f16(x, gin, c["w"], c["bias"], y, gout, Bn * Ho * Wo, Cout, Cin, 9, relu=relu, residual=res, r_geom=gres,
-                             bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True, pe=pe, y_pe=y_pe)
+                             bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True, pe=pe, y_pe=y_pe,
+                             w_tiles=c["w_tiles"] if stride == 1 else None)
 
     def __call__(self, AB, slot=0, shared_b=False):
         """AB (2n,6,H,W) fp16 -> (tokens (n, H/8 * W/8, 512) fp16 before the positional table,

@@ -295,11 +295,21 @@ IGEMM_ROUND_ACC = 2
 class IgemmEpilogue(C.Structure):
     """fp_igemm_epilogue (include/fp_amd.h)"""
     _fields_ = [("bias", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("residual", C.c_void_p),
-                ("r_geom", C.POINTER(IgemmGeom)), ("flags", C.c_int), ("pe", C.c_void_p), ("pe_period", C.c_int), ("y_pe", C.c_void_p)]
+                ("r_geom", C.POINTER(IgemmGeom)), ("flags", C.c_int), ("pe", C.c_void_p), ("pe_period", C.c_int), ("y_pe", C.c_void_p),
+                ("w_tiles", C.c_void_p)]
+
+
+def pack_conv3x3_tiles(w, N, Cin):
+    """(N, 9 * Cin) fp16 conv weight, k ordered (ky, kx, ci) -> the tile-packed copy fp_igemm_f16_fwd's shifted-window kernel reads as
+    contiguous 8 KiB runs (fp_pack_conv3x3_tiles_f16); built once per weight by a plan"""
+    w = _dev(w, torch.float16, "w")
+    out = torch.empty_like(w)
+    _lib.check(_lib.lib().fp_pack_conv3x3_tiles_f16(_ptr(w), _ptr(out), int(N), int(Cin), _stream(w)), "fp_pack_conv3x3_tiles_f16")
+    return out
 
 
 def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residual=None, r_geom=None, bn_scale=None,
-              bn_shift=None, conv_rounding=False, pe=None, y_pe=None):
+              bn_shift=None, conv_rounding=False, pe=None, y_pe=None, w_tiles=None):
     """y = act(f16(epilogue(implicit_gemm(x, w))) (+ residual)) -- see fp_igemm_f16_fwd.  conv_rounding: nn.Conv2d under
     autocast (accumulator rounded to fp16 before the bias add, optional BatchNorm as scale/shift with its own rounding);
     otherwise nn.Linear (one rounding of accumulator + bias).  pe (S, N) f32 + y_pe (M, N) fp16: second output
@@ -314,6 +324,7 @@ def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residu
     ep.r_geom = C.pointer(r_geom) if r_geom is not None else None
     ep.flags = (IGEMM_RELU if relu else 0) | (IGEMM_ROUND_ACC if conv_rounding else 0)
     ep.pe, ep.pe_period, ep.y_pe = _ptr(pe), (int(pe.shape[-2]) if pe is not None else 0), _ptr(y_pe)
+    ep.w_tiles = _ptr(_dev(w_tiles, torch.float16, "w_tiles"))
     st = _lib.lib().fp_igemm_f16_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(y), C.byref(y_geom), int(M), int(N), int(Cin),
                                      int(taps), C.byref(ep), _stream(x))
     _lib.check(st, "fp_igemm_f16_fwd")

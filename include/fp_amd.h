@@ -60,8 +60,9 @@ const char* fp_last_error(void);
  * (foundationpose_amd/_lib.py does and refuses a mismatch).  History of breaks that kept a symbol's name:
  *   200 -> 210 (round 4 / 5): fp_linear_layernorm_fwd takes the FRAGMENT-PACKED weight (fp_pack_linear512_f16) and requires K = 512;
  *                             a caller that still passes the nn.Linear-layout weight gets FP_OK and garbage -- check the version.
- *   210 -> 211 (round 5): + fp_igemm_f16_splitk_fwd / fp_igemm_splitk_workspace_bytes (additions only). */
-#define FP_AMD_ABI_VERSION 211
+ *   210 -> 211 (round 5): + fp_igemm_f16_splitk_fwd / fp_igemm_splitk_workspace_bytes (additions only).
+ *   211 -> 212 (round 5): fp_igemm_epilogue grew by one member at its end (w_tiles); + fp_pack_conv3x3_tiles_f16. */
+#define FP_AMD_ABI_VERSION 212
 int fp_version(void);
 
 /* Utils.py:104-130 make_mesh_tensors: records caller-owned device tensors.
@@ -164,6 +165,8 @@ typedef struct {
   const float* pe;             /* dev (pe_period, N) f32 | NULL: second output y_pe[m, n] = f16(f32(y[m, n]) + pe[m % pe_period, n]), */
   int pe_period;               /*   the PositionalEmbedding add of network_modules.py:133-137 fused into the last conv of the */
   void* y_pe;                  /*   encoder; y_pe is a plain (M, N) fp16 matrix */
+  const void* w_tiles;         /* dev | NULL (since ABI 212): the SAME weights once more, in the tile-packed layout of fp_pack_conv3x3_tiles_f16; */
+                               /*   the shifted-window 3x3 kernel then fetches a k-step's 128 x 32 weight tile as one contiguous 8 KiB run */
 } fp_igemm_epilogue;
 
 /* network_modules.py:37-50 ConvBNReLU / :73-111 ResnetBasicBlock (3x3, pad 1, stride 1|2, eval BatchNorm) and the
@@ -177,6 +180,13 @@ typedef struct {
 int fp_igemm_f16_fwd(const void* x /*dev*/, const fp_igemm_geom* x_geom /*host*/, const void* w /*dev*/, void* y /*dev*/,
                      const fp_igemm_geom* y_geom /*host*/, int M, int N, int Cin, int taps,
                      const fp_igemm_epilogue* epilogue /*host|NULL*/, void* stream);
+
+/* One-time repack of a 3x3 convolution weight (N, 9*Cin) fp16, k ordered (ky, kx, ci), for fp_igemm_epilogue.w_tiles: per block of 128
+ * output channels and per k-step s = (32-channel chunk cc, tap) in the order the shifted-window kernel consumes them (s = 9 cc + tap), the
+ * 128 x 32 weight tile as the 8 KiB LDS image of that kernel (rows of 64 B, 16-byte chunk c of row r at position c ^ ((r >> 2) & 3)):
+ *   w_tiles[((bn * 9 * Cin / 32 + s) * 128 + r) * 32 + 8 * pc + e] = w[128 bn + r][tap * Cin + 32 cc + 8 * (pc ^ ((r >> 2) & 3)) + e].
+ * N % 128 == 0, Cin % 32 == 0; w_tiles has the size of w and must not alias it.  No reference counterpart (a layout, not an operation). */
+int fp_pack_conv3x3_tiles_f16(const void* w /*dev*/, void* w_tiles /*dev*/, int N, int Cin, void* stream);
 
 /* fp_igemm_f16_fwd for launches of a few dozen tiles -- the reference's tracking call (estimater.py:250-268: ONE hypothesis, so the
  * 512 -> 512 convolutions are 400 x 512 x 4608 products = 16 tiles on 256 CUs, each running its whole k loop): the k range is cut into

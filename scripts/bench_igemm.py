@@ -40,9 +40,10 @@ for name, B, Ho, Ci, Co, s in layers:
     r = (torch.randn((B, Ho + 2, Ho + 2, Co), device=dev) * 0.5).half()
     gin = G.image(Ho, Ho, 1, Ci, stride=s, offset=0); gout = G.image(Ho, Ho, 1, Co)
     M = B * Ho * Ho
+    wt = ops.pack_conv3x3_tiles(w, Co, Ci) if (os.environ.get("FP_W_TILES") == "1" and s == 1) else None    # FP_W_TILES=1: tile-packed weights
     for res in (False, True):
         ms = timeit(lambda: ops.igemm_f16(x, gin, w, b, y, gout, M, Co, Ci, 9, relu=True, residual=r if res else None,
-                                          r_geom=gout if res else None, bn_scale=sc, bn_shift=sh, conv_rounding=True))
+                                          r_geom=gout if res else None, bn_scale=sc, bn_shift=sh, conv_rounding=True, w_tiles=wt))
         fl = 2.0 * M * Co * Ci * 9
         print(json.dumps(dict(lib=tag, layer=name, residual=res, ms=round(ms, 4), TFLOPs=round(fl / ms / 1e9, 1))), flush=True)
         if res == (name.startswith("stem") or name.startswith("joint")):   # roughly the mix of the encoder (half the block convs add the identity)

@@ -21,14 +21,15 @@ for (B, H, Ci, Co, res, bn) in ((252, 40, 128, 128, True, True), (126, 40, 256, 
     r = (torch.randn((B, H + 2, H + 2, Co), generator=g) * 0.5).half().to(dev)
     y = torch.zeros((B, H + 2, H + 2, Co), dtype=torch.float16, device=dev)
     M = B * H * H
+    wt = ops.pack_conv3x3_tiles(w, Co, Ci) if os.environ.get("FP_W_TILES") == "1" else None      # FP_W_TILES=1: the tile-packed weight path
     for rep in range(2):
         y.zero_()
         ops.igemm_f16(x, G(H, H, 1, Ci, stride=1, offset=0), w, b, y, G(H, H, 1, Co), M, Co, Ci, 9, relu=True, residual=r if res else None,
-                      r_geom=G(H, H, 1, Co) if res else None, bn_scale=sc if bn else None, bn_shift=sh if bn else None, conv_rounding=True)
+                      r_geom=G(H, H, 1, Co) if res else None, bn_scale=sc if bn else None, bn_shift=sh if bn else None, conv_rounding=True, w_tiles=wt)
     print(f"conv B={B} H={H} {Ci}->{Co} res={res} bn={bn}: {sha(y)} border0={float(y[:, 0].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0}", flush=True)
     if Co == 512:
         tok = torch.zeros((B, H * H, Co), dtype=torch.float16, device=dev); tp = torch.zeros_like(tok)
         pe = torch.randn((H * H, Co), generator=g).to(dev)
         ops.igemm_f16(x, G(H, H, 1, Ci, stride=1, offset=0), w, b, tok, G(H, H, 0, Co), M, Co, Ci, 9, relu=True, residual=r if res else None,
-                      r_geom=G(H, H, 1, Co) if res else None, conv_rounding=True, pe=pe, y_pe=tp)
+                      r_geom=G(H, H, 1, Co) if res else None, conv_rounding=True, pe=pe, y_pe=tp, w_tiles=wt)
         print(f"  tokens: {sha(tok)} {sha(tp)}", flush=True)

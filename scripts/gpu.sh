@@ -60,6 +60,23 @@ PY
     bench_line $name $lib
   done
 }
+t_wtiles() {  # tile-packed conv weights on / off with ONE library: output digests, per-layer rates, the step
+  for v in 0 1 0 1; do
+    echo "-- w_tiles=$v"
+    FP_W_TILES=$v timeout 120 python scripts/cmp_conv_sw.py 2> /dev/null | sha1sum | cut -c1-16 | sed 's/^/   outputs sha1 /'
+    for n in 126 252; do
+      FP_W_TILES=$v FP_N=$n timeout 120 python scripts/bench_igemm.py 2> /dev/null > $O/${TAG}_igemm_wt${v}_$n.log
+      python - $O/${TAG}_igemm_wt${v}_$n.log $n <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
+pick = lambda name, res: next((r["TFLOPs"] for r in rows if r["layer"] == name and r.get("residual", res) == res), 0)
+print(f"   N={sys.argv[2]}: 128->128 {pick('stem 128->128', False):.0f}/{pick('stem 128->128', True):.0f}  256->256 {pick('joint 256->256', False):.0f}/{pick('joint 256->256', True):.0f}  "
+      f"512->512 {pick('joint 512->512', False):.0f}/{pick('joint 512->512', True):.0f}  weighted {rows[-3]['TFLOPs'] if len(rows) > 3 else 0:.0f} TFLOP/s (no residual / residual)")
+PY
+    done
+    FP_AMD_PACKED_CONV_TILES=$v bench_line wtiles$v $PWD/$CS/libfp_amd.so
+  done
+}
 t_probe() {   # MFMA / VALU co-issue probe (scripts/mfma_valu_overlap)
   hipcc --offload-arch=gfx950 -O3 -pthread -o /tmp/mvprobe scripts/mfma_valu_overlap/probe.hip && timeout 300 /tmp/mvprobe > $O/${TAG}_mfma_valu_probe.log 2>&1; cat $O/${TAG}_mfma_valu_probe.log
 }

@@ -58,6 +58,13 @@ def test_argument_errors_are_reported_without_gpu():
     ep = IgemmEpilogue()
     ep.pe = 16                                          # positional table without its output / period
     assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, C.byref(ep), None) == -1
+    # tile-packed conv weights: shape / alias checks of the repack, and w_tiles is refused for a plain GEMM
+    assert lib.fp_pack_conv3x3_tiles_f16(C.c_void_p(16), C.c_void_p(16), 128, 64, None) == -1          # in place
+    assert lib.fp_pack_conv3x3_tiles_f16(C.c_void_p(16), C.c_void_p(32), 100, 64, None) == -1 and b"multiple of 128" in lib.fp_last_error()
+    ep = IgemmEpilogue()
+    ep.w_tiles = 32
+    assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, C.byref(ep), None) == -1
+    assert b"w_tiles" in lib.fp_last_error()
     # split-K variant: workspace size, piece count and workspace checks come before any launch
     assert lib.fp_igemm_splitk_workspace_bytes(400, 512, 12) == 12 * 4 * 4 * 65536 and lib.fp_igemm_splitk_workspace_bytes(400, 100, 2) == 0
     assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, None, 0, C.c_void_p(16), 1 << 20, None) == -1

@@ -730,3 +730,45 @@ def test_scorer_252_vs_exact(scene, dev, gmesh, frame, acc64):
     assert h["abs_err"]["max"] <= max(2.0 * o["abs_err"]["max"], 32 * floor), srep          # 32 fp16 ulps of the logit = 0.0625
     assert h["kendall_tau"] >= o["kendall_tau"] - 0.003 and h["kendall_tau"] >= 0.98, srep
     assert h["top1_rank_in_exact"] <= 1, srep
+
+
+def test_tile_packed_conv_weights_are_the_same_convolution(dev):
+    """round 5: fp_pack_conv3x3_tiles_f16 against its documented layout restated in numpy, and fp_igemm_f16_fwd with epilogue.w_tiles
+    against the same call without it: the shifted-window kernel fetches the same operands from contiguous 8 KiB runs -- the same bits
+    (full and ragged last row tiles, 128 / 256 / 512 channels, residual, BatchNorm, the token layout with the positional output)."""
+    from foundationpose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for N, Cin in ((128, 64), (256, 128), (512, 512)):
+        w = torch.randn((N, 9 * Cin), generator=g).half()
+        packed = ops.pack_conv3x3_tiles(w.to(dev), N, Cin).cpu().numpy().reshape(N // 128, 9 * Cin // 32, 128, 4, 8)
+        wn = w.numpy().reshape(N // 128, 128, 9, Cin // 32, 4, 8)          # [bn][r][tap][cc][lc][e]
+        r = np.arange(128)
+        for bn, s, pc in ((0, 0, 0), (N // 128 - 1, 9 * Cin // 32 - 1, 3), (0, 10, 2), (N // 128 - 1, 5, 1)):
+            cc, tap = divmod(s, 9)
+            lc = pc ^ ((r >> 2) & 3)
+            assert np.array_equal(packed[bn, s, :, pc], wn[bn, r, tap, cc, lc]), (N, Cin, bn, s, pc)
+        assert np.array_equal(np.sort(packed.reshape(-1)), np.sort(w.numpy().reshape(-1)))       # a permutation: nothing lost, nothing doubled
+    G = ops.IgemmGeom.image
+    for (B, H, Ci, Co, res, bn) in ((5, 40, 128, 128, True, True), (3, 40, 256, 256, True, False), (7, 20, 512, 512, False, True), (4, 20, 512, 512, True, True)):
+        x = torch.zeros((B, H + 2, H + 2, Ci), dtype=torch.float16)
+        x[:, 1:-1, 1:-1] = torch.relu(torch.randn((B, H, H, Ci), generator=g) * 0.5).half()
+        x = x.to(dev)
+        w = (torch.randn((Co, 9 * Ci), generator=g) * 0.02).half().to(dev)
+        b = torch.randn(Co, generator=g).half().float().to(dev)
+        sc, sh = (torch.rand(Co, generator=g) + 0.5).to(dev), (torch.randn(Co, generator=g) * 0.1).to(dev)
+        r = (torch.randn((B, H + 2, H + 2, Co), generator=g) * 0.5).half().to(dev)
+        wt = ops.pack_conv3x3_tiles(w, Co, Ci)
+        M = B * H * H
+        outs = []
+        for tiles in (None, wt):
+            y = torch.zeros((B, H + 2, H + 2, Co), dtype=torch.float16, device=dev)
+            ops.igemm_f16(x, G(H, H, 1, Ci, stride=1, offset=0), w, b, y, G(H, H, 1, Co), M, Co, Ci, 9, relu=True, residual=r if res else None,
+                          r_geom=G(H, H, 1, Co) if res else None, bn_scale=sc if bn else None, bn_shift=sh if bn else None, conv_rounding=True,
+                          w_tiles=tiles)
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), (B, H, Ci, Co)
+        assert float(outs[1].abs().max()) > 0
+    # an aliased / misaligned / non-3x3 w_tiles is refused
+    import foundationpose_amd._lib as L
+    with pytest.raises(L.FpAmdError):
+        ops.igemm_f16(x, G(H, H, 1, Ci, stride=1, offset=0), w, b, y, G(H, H, 1, Co), M, Co, Ci, 9, conv_rounding=True, w_tiles=w)
