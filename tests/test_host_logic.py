@@ -137,3 +137,29 @@ def test_small_call_thresholds_keep_the_equalities_of_the_library():
     for rows, cout, cin in layers(1):
         ps = [engine.splitk_pieces(rows * n, cout, cin) for n in range(1, 13)]
         assert all(a >= b for a, b in zip(ps, ps[1:])), ps
+
+
+def test_splitk_slab_order_covers_a_tile_exactly_once():
+    """fp_igemm_f16_splitk_fwd, the slab layout restated in numpy (csrc/igemm.hip: k_igemm_f16<..., SPLITK> stores, k_splitk_epilogue
+    decodes): float4 number ((wave * 16 + (i * 4 + g) * TM + j) * 64 + lane) of a 128 x 128 tile holds the four consecutive channels
+    n = 64 wn + 32 i + 8 g + 4 (lane >> 5) + {0..3} of pixel m = 64 wm + 32 j + (lane & 31) -- the MFMA 32x32x16 accumulator layout
+    (D[channel][pixel]: lane = pixel, register quad g = channels 8 g + 4 (lane >> 5) ..) -- with wave = 2 wm + wn.  Every (m, n) of the
+    tile exactly once, and a wave store instruction (fixed wave, i, g, j; 64 lanes) is 1 KiB of consecutive addresses."""
+    BM = BN = 128
+    TM, NWN, NW = 2, 2, 4
+    seen = np.zeros((BM, BN), dtype=np.int32)
+    for t in range(NW * 8 * TM * 64):                       # float4 index inside the tile's slab, as k_splitk_epilogue decodes it
+        lane = t & 63
+        q = t >> 6
+        j = q % TM; q //= TM
+        g = q & 3; q >>= 2
+        i = q & 1; q >>= 1
+        wid = q % NW
+        wm, wn = divmod(wid, NWN)
+        m = wm * (32 * TM) + j * 32 + (lane & 31)
+        n = wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5)
+        seen[m, n:n + 4] += 1
+        # the store side: dst = slab + ((wid * (8 * TM)) + (i * 4 + g) * TM + j) * 64 + lane
+        assert t == ((wid * (8 * TM)) + (i * 4 + g) * TM + j) * 64 + lane
+    assert (seen == 1).all()
+    assert NW * 8 * TM * 64 * 16 == BM * BN * 4              # bytes of the slab of one (tile, piece) = fp_igemm_splitk_workspace_bytes / (tiles x pieces)
