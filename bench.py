@@ -414,6 +414,12 @@ def main():
 
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
+    # A/B runs of the measuring scripts (scripts/gpu.sh): FP_BENCH_ENGINE="PACKED_CONV_TILES=0,FUSED_FFN=0" flips switches of engine.py
+    # for this process through engine.overrides -- the package itself reads no environment variable
+    ab = os.environ.get("FP_BENCH_ENGINE", "").strip()
+    if ab:
+        from foundationpose_amd import engine
+        engine.overrides(**{k.strip(): int(v) for k, v in (kv.split("=") for kv in ab.split(","))}).__enter__()
     N, R = args.hyps, args.refine_iters
     hyp_mode = args.mode == "hypothesis"
     _log("building scene")

@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime with PyTo
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FP_AMD_LIB") or os.path.join(_HERE, "csrc", "libfp_amd.so")   # FP_AMD_LIB: A/B builds
-ABI_VERSION = 212    # = FP_AMD_ABI_VERSION of include/fp_amd.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 213    # = FP_AMD_ABI_VERSION of include/fp_amd.h (tests/test_abi.py keeps the two in step)
 _lib = None
 
 vp, ci, cf, cd, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t

@@ -315,12 +315,12 @@ static int ig_launch_splitk(const IgemmParams& p, hipStream_t stream) {
   return FP_OK;
 }
 
-static int ig_check_geom(const fp_igemm_geom* g, const char* what) {
+static int ig_check_geom(const fp_igemm_geom* g, const char* what, const char* who) {
   FP_REQUIRE(g->pixels_per_image > 0 && g->width > 0 && g->padded_h > 0 && g->padded_w > 0 && g->cstride > 0 &&
                  g->stride > 0 && g->offset >= 0 && g->coff >= 0 && g->bsplit >= 0,
-             "fp_igemm_f16_fwd: bad %s geometry", what);
+             "%s: bad %s geometry", who, what);
   FP_REQUIRE((g->cstride % 8) == 0 && (g->coff % 8) == 0 && (g->cgroup % 8) == 0,
-             "fp_igemm_f16_fwd: %s channel stride/offset must be multiples of 8 (16-byte rows)", what);
+             "%s: %s channel stride/offset must be multiples of 8 (16-byte rows)", who, what);
   return FP_OK;
 }
 
@@ -385,25 +385,28 @@ static int ig_dispatch(IgemmParams& p, hipStream_t stream) {
 
 
 static int ig_build_params(const void* x, const fp_igemm_geom* x_geom, const void* w, void* y, const fp_igemm_geom* y_geom,
-                           int M, int N, int Cin, int taps, const fp_igemm_epilogue* ep, IgemmParams& p) {
-  FP_REQUIRE(x && w && y && x_geom && y_geom, "fp_igemm_f16_fwd: NULL tensor / geometry");
-  FP_REQUIRE(taps == 1 || taps == 9, "fp_igemm_f16_fwd: taps must be 1 (GEMM) or 9 (3x3 conv), got %d", taps);
-  FP_REQUIRE(N > 0 && N % 128 == 0, "fp_igemm_f16_fwd: N=%d must be a multiple of 128", N);
-  FP_REQUIRE(Cin > 0 && Cin % 64 == 0, "fp_igemm_f16_fwd: Cin=%d must be a multiple of 64", Cin);
+                           int M, int N, int Cin, int taps, const fp_igemm_epilogue* ep, IgemmParams& p, const char* who) {
+  FP_REQUIRE(x && w && y && x_geom && y_geom, "%s: NULL tensor / geometry", who);
+  FP_REQUIRE(taps == 1 || taps == 9, "%s: taps must be 1 (GEMM) or 9 (3x3 conv), got %d", who, taps);
+  FP_REQUIRE(N > 0 && N % 128 == 0, "%s: N=%d must be a multiple of 128", who, N);
+  FP_REQUIRE(Cin > 0 && Cin % 64 == 0, "%s: Cin=%d must be a multiple of 64", who, Cin);
   static const fp_igemm_epilogue no_epilogue = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr};
   const fp_igemm_epilogue& e = ep ? *ep : no_epilogue;
-  FP_REQUIRE(!e.residual || e.r_geom, "fp_igemm_f16_fwd: residual without geometry");
-  FP_REQUIRE((e.bn_scale == nullptr) == (e.bn_shift == nullptr), "fp_igemm_f16_fwd: bn_scale and bn_shift go together");
-  FP_REQUIRE(!e.bn_scale || (e.flags & FP_IGEMM_ROUND_ACC), "fp_igemm_f16_fwd: BatchNorm needs FP_IGEMM_ROUND_ACC (conv semantics)");
-  FP_REQUIRE((e.flags & ~(FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC)) == 0, "fp_igemm_f16_fwd: unknown flags 0x%x", e.flags);
-  FP_REQUIRE((e.pe == nullptr) == (e.y_pe == nullptr) && (!e.pe || e.pe_period > 0), "fp_igemm_f16_fwd: pe, pe_period and y_pe go together");
+  FP_REQUIRE(!e.residual || e.r_geom, "%s: residual without geometry", who);
+  FP_REQUIRE((e.bn_scale == nullptr) == (e.bn_shift == nullptr), "%s: bn_scale and bn_shift go together", who);
+  FP_REQUIRE(!e.bn_scale || (e.flags & FP_IGEMM_ROUND_ACC), "%s: BatchNorm needs FP_IGEMM_ROUND_ACC (conv semantics)", who);
+  FP_REQUIRE((e.flags & ~(FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC | FP_IGEMM_HAS_W_TILES)) == 0, "%s: unknown flags 0x%x", who, e.flags);
+  FP_REQUIRE((e.pe == nullptr) == (e.y_pe == nullptr) && (!e.pe || e.pe_period > 0), "%s: pe, pe_period and y_pe go together", who);
   FP_REQUIRE((((size_t)x | (size_t)w | (size_t)y | (size_t)e.residual | (size_t)e.bias | (size_t)e.bn_scale | (size_t)e.bn_shift |
-               (size_t)e.pe | (size_t)e.y_pe) & 15) == 0, "fp_igemm_f16_fwd: tensors must be 16-byte aligned");
-  if (int err = ig_check_geom(x_geom, "input")) return err;
-  if (int err = ig_check_geom(y_geom, "output")) return err;
-  if (e.residual) if (int err = ig_check_geom(e.r_geom, "residual")) return err;
-  FP_REQUIRE(!e.w_tiles || (taps == 9 && (((size_t)e.w_tiles) & 15) == 0 && e.w_tiles != w), "fp_igemm_f16_fwd: w_tiles is for 3x3 convolutions, 16-byte aligned, not w itself");
-  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.Wpk = (const _Float16*)e.w_tiles; p.bias = e.bias; p.bn_scale = e.bn_scale; p.bn_shift = e.bn_shift;
+               (size_t)e.pe | (size_t)e.y_pe) & 15) == 0, "%s: tensors must be 16-byte aligned", who);
+  if (int err = ig_check_geom(x_geom, "input", who)) return err;
+  if (int err = ig_check_geom(y_geom, "output", who)) return err;
+  if (e.residual) if (int err = ig_check_geom(e.r_geom, "residual", who)) return err;
+  // w_tiles is a trailing member added in ABI 212: it is READ only when the caller says the struct has it (a native caller compiled
+  // against an older header passes a shorter struct and can never set the bit)
+  const void* w_tiles = (e.flags & FP_IGEMM_HAS_W_TILES) ? e.w_tiles : nullptr;
+  FP_REQUIRE(!w_tiles || (taps == 9 && (((size_t)w_tiles) & 15) == 0 && w_tiles != w), "%s: w_tiles is for 3x3 convolutions, 16-byte aligned, not w itself", who);
+  p.A = (const _Float16*)x; p.Wt = (const _Float16*)w; p.Wpk = (const _Float16*)w_tiles; p.bias = e.bias; p.bn_scale = e.bn_scale; p.bn_shift = e.bn_shift;
   p.R = (const _Float16*)e.residual; p.Y = (_Float16*)y;
   p.pe = e.pe; p.Ype = (_Float16*)e.y_pe; p.pe_period = e.pe_period;
   p.M = M; p.N = N; p.Cin = Cin; p.taps = taps; p.relu = (e.flags & FP_IGEMM_RELU) ? 1 : 0;
@@ -418,7 +421,7 @@ extern "C" int fp_igemm_f16_fwd(const void* x, const fp_igemm_geom* x_geom, cons
   FP_REQUIRE(M >= 0, "fp_igemm_f16_fwd: M < 0");
   if (M == 0) return FP_OK;
   IgemmParams p;
-  if (int err = ig_build_params(x, x_geom, w, y, y_geom, M, N, Cin, taps, ep, p)) return err;
+  if (int err = ig_build_params(x, x_geom, w, y, y_geom, M, N, Cin, taps, ep, p, "fp_igemm_f16_fwd")) return err;
   return ig_dispatch(p, (hipStream_t)stream);
 }
 
@@ -433,7 +436,8 @@ extern "C" int fp_igemm_f16_splitk_fwd(const void* x, const fp_igemm_geom* x_geo
   FP_REQUIRE(M >= 0, "fp_igemm_f16_splitk_fwd: M < 0");
   if (M == 0) return FP_OK;
   IgemmParams p;
-  if (int err = ig_build_params(x, x_geom, w, y, y_geom, M, N, Cin, taps, ep, p)) return err;
+  if (int err = ig_build_params(x, x_geom, w, y, y_geom, M, N, Cin, taps, ep, p, "fp_igemm_f16_splitk_fwd")) return err;
+  FP_REQUIRE(!p.Wpk, "fp_igemm_f16_splitk_fwd: w_tiles is the operand layout of the shifted-window kernel; the split-K kernels do not take it");
   const int nk = taps * (Cin / SK_BK);
   FP_REQUIRE(splits >= 1 && splits <= nk, "fp_igemm_f16_splitk_fwd: splits=%d must be in [1, %d] (k-steps of 64)", splits, nk);
   const size_t need = ig_splitk_bytes(M, N, splits);

@@ -109,11 +109,20 @@ def register_hypothesis_parallel(refiner, scorer, rgb, depth, K, poses_all, xyz_
     poses_all = torch.as_tensor(poses_all)
     N = poses_all.shape[0]
     b, e = shard_bounds(N, world)[rank]
-    local, _ = refiner.predict(rgb, depth, K, poses_all[b:e], xyz_map, mesh=mesh, mesh_tensors=mesh_tensors,
-                               mesh_diameter=mesh_diameter, iteration=iteration, shared_translation=shared_translation)
-    ex = FeaturePoseExchange(local, N, group, collective, world_rank)
-    scores, _ = scorer.predict(rgb, depth, K, local, mesh=mesh, mesh_tensors=mesh_tensors,
-                               mesh_diameter=mesh_diameter, feature_exchange=ex)
+    # a shard must return the bits of the single batch whatever its size: with more than one rank no call takes the small-call
+    # kernels (split-K convolutions / two-stream heads, engine.py), whose summation order is another one.  (A single batch of <= 12
+    # hypotheses does take them; sharding such a call over ranks is not something the bit-equality contract covers.)
+    saved = getattr(refiner, "small_calls", True), getattr(scorer, "small_calls", True)
+    if world > 1:
+        refiner.small_calls = scorer.small_calls = False
+    try:
+        local, _ = refiner.predict(rgb, depth, K, poses_all[b:e], xyz_map, mesh=mesh, mesh_tensors=mesh_tensors,
+                                   mesh_diameter=mesh_diameter, iteration=iteration, shared_translation=shared_translation)
+        ex = FeaturePoseExchange(local, N, group, collective, world_rank)
+        scores, _ = scorer.predict(rgb, depth, K, local, mesh=mesh, mesh_tensors=mesh_tensors,
+                                   mesh_diameter=mesh_diameter, feature_exchange=ex)
+    finally:
+        refiner.small_calls, scorer.small_calls = saved
     order = scores.argsort(descending=True)
     return ex.poses_all[order], scores[order], order
 

@@ -34,8 +34,6 @@ policy that tests/test_gpu_amp.py puts next to the HIP plan and the oracle, and 
 """
 import contextlib
 
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -50,8 +48,8 @@ USE_MIOPEN = False
 
 # out_proj + residual + LayerNorm of the refiner's encoder layers as ONE kernel (csrc/linear_ln.hip, fp_linear_layernorm_fwd):
 # bit-identical to the two launches it replaces (tests/test_gpu_parity.py::test_linear_layernorm_is_the_two_kernel_path) and
-# 0.6-1.4 % of the step faster.  FP_AMD_FUSED_LN=0 goes back to fp_igemm_f16_fwd + fp_layernorm_res_fwd.
-FUSED_OUT_PROJ_LN = os.environ.get("FP_AMD_FUSED_LN", "1") != "0"
+# 0.6-1.4 % of the step faster.  overrides(FUSED_OUT_PROJ_LN=False) goes back to fp_igemm_f16_fwd + fp_layernorm_res_fwd.
+FUSED_OUT_PROJ_LN = True
 
 
 # linear1 + ReLU + linear2 + residual + norm2 + token mean of the refiner's encoder layers as ONE launch (+ a finish kernel;
@@ -59,19 +57,19 @@ FUSED_OUT_PROJ_LN = os.environ.get("FP_AMD_FUSED_LN", "1") != "0"
 # mean is summed in another fixed fp32 order, so it passes the parity gates against the exactly-rounded yardstick
 # (tests/test_gpu_amp.py) rather than an equality test: distances to the yardstick unchanged to three digits
 # (profiles/r04_parity_amp.json against r04_parity_amp_fused_ffn.json), 35.9 -> 35.1 ms per bench step (profiles/r04_b_bench_*).
-# FP_AMD_FUSED_FFN=0 goes back to 2 x fp_igemm_f16_fwd + fp_colmean_f16_fwd.
-FUSED_FFN = os.environ.get("FP_AMD_FUSED_FFN", "1") != "0"
+# overrides(FUSED_FFN=False) goes back to 2 x fp_igemm_f16_fwd + fp_colmean_f16_fwd.
+FUSED_FFN = True
 
 
 # The in_proj of the self-attention blocks (512 -> 1536) on the row-owning tile (csrc/linear_ln.hip, fp_linear512_f16_fwd): the 128 x 512
 # input tile of a workgroup is fetched once for the three column blocks, weights come fragment-packed from L2 into registers.  The bits
-# of fp_igemm_f16_fwd (tests/test_gpu_parity.py::test_linear512_is_the_igemm_linear).  FP_AMD_ROWS_QKV=0 goes back to fp_igemm_f16_fwd;
-# launches below ROWS_QKV_MIN_ROWS rows (the scorer's cross-hypothesis attention: 252 rows) stay there as well.
-ROWS_QKV = os.environ.get("FP_AMD_ROWS_QKV", "1") != "0"
+# of fp_igemm_f16_fwd (tests/test_gpu_parity.py::test_linear512_is_the_igemm_linear).  overrides(ROWS_QKV=False) goes back to
+# fp_igemm_f16_fwd; launches below ROWS_QKV_MIN_ROWS rows (the scorer's cross-hypothesis attention: 252 rows) stay there as well.
+ROWS_QKV = True
 ROWS_QKV_MIN_ROWS = 4096
 # round 5: the encoder's stride-1 3x3 convolutions hand fp_igemm_f16_fwd a tile-packed copy of their weights as well (epilogue.w_tiles): the
 # shifted-window kernel then stages a k-step's weight tile from one contiguous 8 KiB run.  Same operands, same order: the same bits.
-PACKED_CONV_TILES = os.environ.get("FP_AMD_PACKED_CONV_TILES", "1") != "0"
+PACKED_CONV_TILES = True
 
 
 def _conv_backend():
@@ -209,9 +207,39 @@ def _conv_params(sd, conv_p, bn_p):
 # measured (scripts/bench_small_batches.py, profiles/r05_k_small_batches.log): predict(n, 2 iterations) 1.90 -> 1.05 ms at n = 1, 1.90 -> 1.21 at
 # 4, 1.93 -> 1.39 at 8, 2.02 -> 1.71 at 12, 2.05 -> 1.96 at 16, slower from 24 on.  Must stay below the sub-batch minimum (overlap.SubBatches
 # min_rows = 32): a call that is split into sub-batches never takes this path, so the parts of a call and the whole call always agree.
-SPLITK_MAX_HYPS = int(os.environ.get("FP_AMD_SPLITK_MAX_HYPS", "12"))
-HEADS_TWO_STREAMS_MAX_HYPS = int(os.environ.get("FP_AMD_HEADS_TWO_STREAMS_MAX_HYPS", "12"))   # RefinePlan: see __call__
+SPLITK_MAX_HYPS = 12
+HEADS_TWO_STREAMS_MAX_HYPS = 12   # RefinePlan: see __call__
 SPLITK_TARGET_WGS = 384        # (tile, piece) workgroups a launch should have: 1.5 per CU
+# the hard ceiling of both thresholds: overlap.SubBatches' default min_rows (a call of >= 2 x 32 hypotheses is split into sub-batches)
+SMALL_CALL_CEILING = 31
+
+_SWITCHES = ("FUSED_OUT_PROJ_LN", "FUSED_FFN", "ROWS_QKV", "PACKED_CONV_TILES", "SPLITK_MAX_HYPS", "HEADS_TWO_STREAMS_MAX_HYPS")
+
+
+@contextlib.contextmanager
+def overrides(**kw):
+    """Test / A-B hook (round 6: the release package reads NO environment variable -- which kernels and which summation order a
+    call runs are fixed by the constants above).  `with engine.overrides(SPLITK_MAX_HYPS=0): ...` changes a switch for plans BUILT
+    AND RUN inside the block and restores it; the small-call thresholds are refused above SMALL_CALL_CEILING, where the parts of a
+    sub-batched call and the whole call would no longer see one arithmetic."""
+    g = globals()
+    for k, v in kw.items():
+        if k not in _SWITCHES:
+            raise KeyError(f"engine.overrides: unknown switch {k!r} (known: {', '.join(_SWITCHES)})")
+        if k.endswith("_MAX_HYPS") and not (0 <= int(v) <= SMALL_CALL_CEILING):
+            raise ValueError(f"engine.overrides: {k} = {v} is outside 0..{SMALL_CALL_CEILING}")
+    saved = {k: g[k] for k in kw}
+    g.update(kw)
+    try:
+        yield
+    finally:
+        g.update(saved)
+
+
+def small_call(n, limit):
+    """is a call of n hypotheses a small call under threshold `limit`?  Clamped at use: whatever a test set, never at or above the
+    sub-batch minimum"""
+    return n <= min(int(limit), SMALL_CALL_CEILING)
 
 
 def splitk_pieces(rows, cout, cin):
@@ -248,14 +276,15 @@ class _HipEncoder:
         self.device = device
         self._bufs = {}
 
-    def _buffers(self, n, H, W, slot):
-        key = (n, H, W, slot)
+    def _buffers(self, n, H, W, slot, small=True):
+        small = bool(small) and small_call(n, SPLITK_MAX_HYPS)
+        key = (n, H, W, slot, small)
         b = self._bufs.get(key)
         if b is None:
             z = lambda *shape: torch.zeros(shape, dtype=torch.float16, device=self.device)
             h1, w1, h2, w2, h3, w3 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
             sk = None
-            if n <= SPLITK_MAX_HYPS:
+            if small:
                 need = max(ops.igemm_splitk_workspace_bytes(r, co, splitk_pieces(r, co, ci))
                            for r, co, ci in ((2 * n * h2 * w2, 128, 64), (2 * n * h2 * w2, 128, 128), (n * h2 * w2, 256, 256),
                                              (n * h3 * w3, 512, 256), (n * h3 * w3, 512, 512)))
@@ -284,7 +313,7 @@ class _HipEncoder:
                              bn_scale=c["scale"], bn_shift=c["shift"], conv_rounding=True, pe=pe, y_pe=y_pe,
                              w_tiles=c["w_tiles"] if stride == 1 else None)
 
-    def __call__(self, AB, slot=0, shared_b=False):
+    def __call__(self, AB, slot=0, shared_b=False, small_calls=True):
         """AB (2n,6,H,W) fp16 -> (tokens (n, H/8 * W/8, 512) fp16 before the positional table,
         x16 = f16(f32(tokens) + pe): the in_proj operand, written by the same epilogue).
         shared_b: AB is (n+1,6,H,W) -- n rendered crops and ONE observed crop that all n pairs share (the first refine
@@ -293,7 +322,7 @@ class _HipEncoder:
         the same order, so the result is bit-identical to feeding n copies."""
         n2, _, H, W = AB.shape
         n = n2 - 1 if shared_b else n2 // 2
-        b = self._buffers(n, H, W, slot)
+        b = self._buffers(n, H, W, slot, small_calls)
         h1, w1, h2, w2, h3, w3 = b["dims"]
         G = ops.IgemmGeom.image
         ops.conv7x7s2_bn_relu(AB, self.c1_w, self.c1_b, self.c1_scale, self.c1_shift, b["P1"][:n2], 1)
@@ -363,15 +392,16 @@ class _HipMHA:
         self.small_calls = small_calls
         self._sk = {}
 
-    def context(self, x16):
-        """softmax(q k^T / sqrt(d)) v with heads merged, before the output projection: (Bn, L, D) fp16"""
+    def context(self, x16, slot=0, small_calls=True):
+        """softmax(q k^T / sqrt(d)) v with heads merged, before the output projection: (Bn, L, D) fp16.  slot: as for the encoder's
+        activation sets -- callers that overlap on different streams must not share the split-K slab"""
         Bn, L, D = x16.shape
         if ROWS_QKV and self.qkv_p is not None and Bn * L >= ROWS_QKV_MIN_ROWS:
             qkv = ops.linear512(x16, self.qkv_p, self.qkv.b)
-        elif self.small_calls and Bn <= SPLITK_MAX_HYPS and D % 64 == 0 and D // 64 >= 4:
+        elif self.small_calls and small_calls and small_call(Bn, SPLITK_MAX_HYPS) and D % 64 == 0 and D // 64 >= 4:
             M, No = Bn * L, self.qkv.w.shape[0]
             pieces = max(1, min(D // 64 // 2, round(SPLITK_TARGET_WGS / (-(-M // 128) * (No // 128)))))
-            key = (M, No, pieces, x16.device)
+            key = (M, No, pieces, x16.device, slot)
             ws = self._sk.get(key)
             if ws is None:
                 ws = self._sk[key] = torch.empty(ops.igemm_splitk_workspace_bytes(M, No, pieces), dtype=torch.uint8, device=x16.device)
@@ -382,8 +412,8 @@ class _HipMHA:
             qkv = self.qkv(x16)
         return ops.attention_f16(qkv.reshape(Bn, L, 3 * D), self.nhead, fp16_scores=self.fp16_scores)
 
-    def __call__(self, x16):
-        return self.out(self.context(x16))
+    def __call__(self, x16, slot=0, small_calls=True):
+        return self.out(self.context(x16, slot, small_calls))
 
 
 class _HipEncoderLayer:
@@ -399,14 +429,14 @@ class _HipEncoderLayer:
         # fragment-packed copies for the row-owning fused kernels (csrc/linear_ln.hip), which read weights from L2 into registers
         self.out_p, self.l1_p, self.l2_p = (ops.PackedLinear512(m.w) for m in (self.att.out, self.l1, self.l2))
 
-    def pooled(self, tok16, x16, pe):
+    def pooled(self, tok16, x16, pe, slot=0, small_calls=True):
         """-> mean over the tokens of the layer output, (N, 512) fp32"""
         if FUSED_OUT_PROJ_LN:
             # out_proj + residual + norm1 in one launch, the projection staying on chip (fp_linear_layernorm_fwd): the same bits
-            y32, y16 = ops.linear_layernorm_res(self.att.context(x16), self.out_p, self.att.out.b, self.n1[0], self.n1[1], 1e-5,
+            y32, y16 = ops.linear_layernorm_res(self.att.context(x16, slot, small_calls), self.out_p, self.att.out.b, self.n1[0], self.n1[1], 1e-5,
                                                 tok16=tok16, pe=pe)
         else:
-            sa = self.att(x16)                                                   # fp16
+            sa = self.att(x16, slot, small_calls)                                # fp16
             y32, y16 = ops.layernorm_res(sa, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)   # LN(x + sa): fp32 stream + fp16 copy
         if FUSED_FFN and y16.shape[1] % 16 == 0:
             return ops.ffn_layernorm_mean(y16, self.l1_p, self.l1.b, self.l2_p, self.l2.b, y32, self.n2[0], self.n2[1], 1e-5)
@@ -425,6 +455,10 @@ def _dev_sd(module_or_sd, device):
 
 
 class RefinePlan:
+    # False: a call of <= SPLITK_MAX_HYPS hypotheses runs the kernels (and the summation order) of a large call -- what the shards of
+    # a multi-rank call ask for, so that a shard returns the bits of the single batch whatever its size (dist.py)
+    small_calls = True
+
     def __init__(self, model, device, precision="fp16", channels_last=True):
         _check_precision(precision)
         self.dtype = torch.float16 if precision == "fp16" else torch.float32
@@ -449,10 +483,14 @@ class RefinePlan:
         """the side stream the rotation head of a SMALL call runs on, or None: calls of more than HEADS_TWO_STREAMS_MAX_HYPS
         hypotheses fill the chip by themselves (and the side stream belongs to their sub-batches), a per-kernel timing pass wants
         one stream, and a side stream that shares the main stream's hardware queue buys nothing"""
-        if not getattr(self, "two_stream_heads", True) or tok16.shape[0] > HEADS_TWO_STREAMS_MAX_HYPS or tok16.device.type != "cuda" \
-                or ops.KernelTimers.active is not None:
+        if not getattr(self, "two_stream_heads", True) or not self.small_calls or not small_call(tok16.shape[0], HEADS_TWO_STREAMS_MAX_HYPS) \
+                or tok16.device.type != "cuda" or ops.KernelTimers.active is not None:
             return None
         from . import overlap
+        # the probe of a side stream (spin kernels, the rasteriser canary) synchronises: never inside a stream capture.  The predictors
+        # reserve the stream when they build the plan; a capture that still gets here first stays on one stream
+        if torch.cuda.is_current_stream_capturing() and not overlap.reserved(tok16.device, 1):
+            return None
         if not overlap.side_streams_overlap(tok16.device, 1):
             return None
         return overlap.reserve_streams(tok16.device, 1)[0]
@@ -471,14 +509,15 @@ class RefinePlan:
                 o = self.module(AB[:n], AB[n:])
             return {k: v.float() for k, v in o.items()}                 # predict_pose_refine.py:192-193
         if self.hip:
-            tok16, x16 = self.enc(AB, slot, shared_b=shared_b)
+            sc = self.small_calls
+            tok16, x16 = self.enc(AB, slot, shared_b=shared_b, small_calls=sc)
             # Linear and the token mean commute: mean_t(x_t W^T + b) = (mean_t x_t) W^T + b, so the 512 -> 3|6 head
             # runs on N rows instead of N*400 (refine_network.py:90-91); the result is held in fp16 by the reference
-            run = lambda name: self.heads[name][1](self.heads[name][0].pooled(tok16, x16, self.enc.pe), round_f16=True)
+            run = lambda name, hslot: self.heads[name][1](self.heads[name][0].pooled(tok16, x16, self.enc.pe, hslot, sc), round_f16=True)
             side = self._head_side_stream(tok16)
             if side is None:
                 for name in self.heads:
-                    out[name] = run(name)
+                    out[name] = run(name, slot)
                 return out
             # round 5: a call of a few hypotheses (the reference's track_one: ONE) is a chain of ~100 latency-bound launches on an
             # empty chip, and the two heads are independent given the tokens (refine_network.py:90-91): the rotation head runs on the
@@ -487,11 +526,12 @@ class RefinePlan:
             cur = torch.cuda.current_stream(tok16.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                out["rot"] = run("rot")
-            out["trans"] = run("trans")
+                out["rot"] = run("rot", (slot, "side"))
+            out["trans"] = run("trans", slot)
             cur.wait_stream(side)
-            for t in (tok16, x16, out["rot"]):
+            for t in (tok16, x16):              # allocated on the main stream, read on the side stream
                 t.record_stream(side)
+            out["rot"].record_stream(cur)       # allocated on the side stream, read on the main stream after the join
             return out
         with _conv_backend():
             tok = self.enc(AB)
@@ -501,6 +541,8 @@ class RefinePlan:
 
 
 class ScorePlan:
+    small_calls = True          # see RefinePlan
+
     def __init__(self, model, device, precision="fp16", channels_last=True):
         _check_precision(precision)
         self.dtype = torch.float16 if precision == "fp16" else torch.float32
@@ -533,9 +575,9 @@ class ScorePlan:
                 return out
             return f
         if self.hip:
-            _, x16 = self.enc(AB, slot)
+            _, x16 = self.enc(AB, slot, small_calls=self.small_calls)
             # out_proj and the token mean commute (score_network.py:73-74): pool the attention output, project N rows
-            return self.att.out_rows(ops.colmean_f16(self.att.context(x16)), out_f16=True, out=out)
+            return self.att.out_rows(ops.colmean_f16(self.att.context(x16, slot, self.small_calls)), out_f16=True, out=out)
         with _conv_backend():
             tok = self.enc(AB)
         f = self.att(tok).float().mean(dim=1)

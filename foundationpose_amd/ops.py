@@ -290,6 +290,7 @@ class IgemmGeom(C.Structure):
 
 IGEMM_RELU = 1
 IGEMM_ROUND_ACC = 2
+IGEMM_HAS_W_TILES = 4
 
 
 class IgemmEpilogue(C.Structure):
@@ -322,7 +323,7 @@ def igemm_f16(x, x_geom, w, bias, y, y_geom, M, N, Cin, taps, relu=False, residu
     ep.bias, ep.bn_scale, ep.bn_shift = _ptr(b), _ptr(sc), _ptr(sh)
     ep.residual = _ptr(r)
     ep.r_geom = C.pointer(r_geom) if r_geom is not None else None
-    ep.flags = (IGEMM_RELU if relu else 0) | (IGEMM_ROUND_ACC if conv_rounding else 0)
+    ep.flags = (IGEMM_RELU if relu else 0) | (IGEMM_ROUND_ACC if conv_rounding else 0) | IGEMM_HAS_W_TILES
     ep.pe, ep.pe_period, ep.y_pe = _ptr(pe), (int(pe.shape[-2]) if pe is not None else 0), _ptr(y_pe)
     ep.w_tiles = _ptr(_dev(w_tiles, torch.float16, "w_tiles"))
     st = _lib.lib().fp_igemm_f16_fwd(_ptr(x), C.byref(x_geom), _ptr(w), _ptr(y), C.byref(y_geom), int(M), int(N), int(Cin),

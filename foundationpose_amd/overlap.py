@@ -133,6 +133,13 @@ def _exact_next_to_gemm(st, device, launches=24):
     return bad == 0
 
 
+def reserved(device, k=1):
+    """have the first k side streams of `device` been created and probed already? (no side effect: safe inside a stream capture)"""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return len(_SIDE.get(idx, ())) >= k
+
+
 def side_streams_overlap(device, k=1):
     """True if the first k side streams of `device` were measured to run beside the main stream"""
     device = torch.device(device)

@@ -161,6 +161,7 @@ class PoseRefinePredictor:
         self.model.load_state_dict(state_dict)
         self.model.to(self.device).eval()
         self._plan = None
+        self.small_calls = True      # engine.RefinePlan.small_calls: False = a few-hypothesis call runs the kernels of a large one (dist.py)
         self.last_trans_update = None
         self.last_rot_update = None
 
@@ -170,6 +171,12 @@ class PoseRefinePredictor:
             self._plan = RefinePlan(self.model, dev, **self._plan_opts)
             self._plan.two_stream_heads = self.sub.n_streams > 1      # n_streams=1 switches every use of the side stream off
             self._plan_dev = dev
+            if self._plan.hip and self._plan.two_stream_heads and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                # create and probe the side stream NOW (spin kernels + the rasteriser canary synchronise): the first small call -- the
+                # reference's track_one -- must not pay for it, and a capture must never meet an unprobed stream (engine._head_side_stream)
+                from .overlap import reserve_streams
+                reserve_streams(dev, 1)
+        self._plan.small_calls = bool(self.small_calls)
         return self._plan
 
     def _loop_constants(self):
@@ -268,7 +275,7 @@ class PoseRefinePredictor:
         handle = get_mesh_handle(mesh_tensors)
         parts = tuple(self.sub.parts(N, dev))
         key = (N, int(iteration), H, W, np.asarray(K, dtype=np.float64).tobytes(), id(handle), float(mesh_diameter),
-               bool(shared_translation), parts, bool(self.sub.serial), dev.index)
+               bool(shared_translation), parts, bool(self.sub.serial), dev.index, bool(plan.small_calls))
 
         def build():
             oh, ow, _, _ = self._loop_constants()

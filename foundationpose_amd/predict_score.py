@@ -80,12 +80,14 @@ class ScorePredictor:
         self.model.load_state_dict(state_dict)
         self.model.to(self.device).eval()
         self._plan = None
+        self.small_calls = True      # engine.ScorePlan.small_calls: False = a few-hypothesis call runs the kernels of a large one (dist.py)
 
     def plan(self):
         dev = next(self.model.parameters()).device
         if self._plan is None or self._plan_dev != dev:
             self._plan = ScorePlan(self.model, dev, **self._plan_opts)
             self._plan_dev = dev
+        self._plan.small_calls = bool(self.small_calls)
         return self._plan
 
     @torch.inference_mode()
@@ -100,7 +102,8 @@ class ScorePredictor:
         handle = get_mesh_handle(mesh_tensors)
         parts = tuple(self.sub.parts(N, dev))
         H, W = int(depth_t.shape[0]), int(depth_t.shape[1])
-        key = (N, H, W, np.asarray(K, dtype=np.float64).tobytes(), id(handle), float(mesh_diameter), parts, bool(self.sub.serial), dev.index)
+        key = (N, H, W, np.asarray(K, dtype=np.float64).tobytes(), id(handle), float(mesh_diameter), parts, bool(self.sub.serial), dev.index,
+               bool(plan.small_calls))
 
         def build():
             oh, ow = int(self.cfg["input_resize"][0]), int(self.cfg["input_resize"][1])

@@ -147,3 +147,24 @@ def _calibration_overlay(kind, sd):
         if pre == kind and key in sd:
             out[key] = torch.from_numpy(v).to(sd[key].dtype).reshape(sd[key].shape)
     return out
+
+
+TRAINED_REFINER_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "standin_trained_refiner.npz")
+
+
+def trained_refiner_state_dict(path=None):
+    """Round 6: the stand-in RefineNet TRAINED on the synthetic scene of the parity tests (tests/golden/train_standin_refiner.py: the
+    product's nn.Module under autocast on PyTorch-ROCm, perturbations of the ground-truth pose rendered by fp_render_crops, the
+    normalised delta of predict_pose_refine.py:195-234 as the target) -- a genuine contraction towards the observed pose, which is what
+    the reference's released checkpoint is and what no random trunk can be.  The file holds matrices and kernels in float16 (the cast
+    autocast applies to them anyway, made once) and vectors in float32; returned as a float32 state_dict with the reference's keys."""
+    import numpy as np
+    path = path or TRAINED_REFINER_FILE
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: the trained stand-in refiner is made by tests/golden/train_standin_refiner.py on a GPU box")
+    z = np.load(path)
+    out = {}
+    for k in z.files:
+        v = torch.from_numpy(z[k])
+        out[k] = v.float() if v.dtype.is_floating_point else v
+    return out

@@ -61,8 +61,10 @@ const char* fp_last_error(void);
  *   200 -> 210 (round 4 / 5): fp_linear_layernorm_fwd takes the FRAGMENT-PACKED weight (fp_pack_linear512_f16) and requires K = 512;
  *                             a caller that still passes the nn.Linear-layout weight gets FP_OK and garbage -- check the version.
  *   210 -> 211 (round 5): + fp_igemm_f16_splitk_fwd / fp_igemm_splitk_workspace_bytes (additions only).
- *   211 -> 212 (round 5): fp_igemm_epilogue grew by one member at its end (w_tiles); + fp_pack_conv3x3_tiles_f16. */
-#define FP_AMD_ABI_VERSION 212
+ *   211 -> 212 (round 5): fp_igemm_epilogue grew by one member at its end (w_tiles); + fp_pack_conv3x3_tiles_f16.
+ *   212 -> 213 (round 6): w_tiles is read only when flags has FP_IGEMM_HAS_W_TILES (a 212 caller that sets w_tiles without the bit
+ *                         gets the plain weight path: correct, slower); fp_igemm_f16_splitk_fwd refuses w_tiles instead of ignoring it. */
+#define FP_AMD_ABI_VERSION 213
 int fp_version(void);
 
 /* Utils.py:104-130 make_mesh_tensors: records caller-owned device tensors.
@@ -150,6 +152,8 @@ typedef struct {
 } fp_igemm_geom;
 
 #define FP_IGEMM_RELU 1      /* ReLU after the residual add */
+#define FP_IGEMM_HAS_W_TILES 4 /* the struct has the trailing member w_tiles and the library may read it (ABI 213: a caller compiled
+                                 against the ABI-211 header passes a shorter struct, never sets the bit, and is never read past its end) */
 #define FP_IGEMM_ROUND_ACC 2 /* nn.Conv2d semantics: the accumulator is rounded to fp16 BEFORE the bias is added (ATen adds the
                                 bias to the fp16 convolution output) and BatchNorm, if given, rounds once more; without the
                                 flag: nn.Linear semantics, one rounding of accumulator + bias */
@@ -161,11 +165,11 @@ typedef struct {
   const float* bn_shift;
   const void* residual;        /* dev fp16 | NULL: `out += identity` (network_modules.py:107), rounded to fp16 */
   const fp_igemm_geom* r_geom; /* host: addressing of the residual */
-  int flags;                   /* FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC */
+  int flags;                   /* FP_IGEMM_RELU | FP_IGEMM_ROUND_ACC | FP_IGEMM_HAS_W_TILES */
   const float* pe;             /* dev (pe_period, N) f32 | NULL: second output y_pe[m, n] = f16(f32(y[m, n]) + pe[m % pe_period, n]), */
   int pe_period;               /*   the PositionalEmbedding add of network_modules.py:133-137 fused into the last conv of the */
   void* y_pe;                  /*   encoder; y_pe is a plain (M, N) fp16 matrix */
-  const void* w_tiles;         /* dev | NULL (since ABI 212): the SAME weights once more, in the tile-packed layout of fp_pack_conv3x3_tiles_f16; */
+  const void* w_tiles;         /* dev | NULL (since ABI 212; read only with FP_IGEMM_HAS_W_TILES): the SAME weights once more, in the tile-packed layout of fp_pack_conv3x3_tiles_f16; */
                                /*   the shifted-window 3x3 kernel then fetches a k-step's 128 x 32 weight tile as one contiguous 8 KiB run */
 } fp_igemm_epilogue;
 

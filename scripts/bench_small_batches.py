@@ -18,8 +18,8 @@ poses = torch.as_tensor(sc["poses"], device=dev)
 rows = []
 for n in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
     res = {}
-    for name, T in (("plain", 0), ("splitk", 64)):
-        engine.SPLITK_MAX_HYPS = T
+    for name, T in (("plain", 0), ("splitk", engine.SMALL_CALL_CEILING)):
+        engine.SPLITK_MAX_HYPS = T            # a measuring script: no restore; the product path is engine.overrides()
         ref = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0), device=dev, graph=False)
         run = lambda: ref.predict(rgb_t, depth_t, sc["K"], poses[:n], xyz_t, mesh=sc["mesh"], mesh_tensors=sc["gm"], mesh_diameter=sc["diameter"], iteration=2)
         for _ in range(3):

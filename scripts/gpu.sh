@@ -74,7 +74,7 @@ print(f"   N={sys.argv[2]}: 128->128 {pick('stem 128->128', False):.0f}/{pick('s
       f"512->512 {pick('joint 512->512', False):.0f}/{pick('joint 512->512', True):.0f}  weighted {rows[-3]['TFLOPs'] if len(rows) > 3 else 0:.0f} TFLOP/s (no residual / residual)")
 PY
     done
-    FP_AMD_PACKED_CONV_TILES=$v bench_line wtiles$v $PWD/$CS/libfp_amd.so
+    FP_BENCH_ENGINE="PACKED_CONV_TILES=$v" bench_line wtiles$v $PWD/$CS/libfp_amd.so
   done
 }
 t_probe() {   # MFMA / VALU co-issue probe (scripts/mfma_valu_overlap)

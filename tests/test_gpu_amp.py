@@ -729,7 +729,13 @@ def test_scorer_252_vs_exact(scene, dev, gmesh, frame, acc64):
     # maximum -- which is one draw and depends on the host's torch kernels -- or 32 ulps, whichever is larger
     assert h["abs_err"]["max"] <= max(2.0 * o["abs_err"]["max"], 32 * floor), srep          # 32 fp16 ulps of the logit = 0.0625
     assert h["kendall_tau"] >= o["kendall_tau"] - 0.003 and h["kendall_tau"] >= 0.98, srep
-    assert h["top1_rank_in_exact"] <= 1, srep
+    # the best hypothesis IS the exact best one (estimater.py:226-229 keeps poses[argmax]) -- unless the exact ranking itself cannot tell
+    # its top two apart at the precision the reference holds a logit in: within 2 fp16 ulps of each other, either may win
+    order = np.argsort(-sx)
+    gap = float(sx[order[0]] - sx[order[1]])
+    near_tie = gap <= 2.0 * float(ulp16(abs(sx[order[0]] - 100.0)))
+    srep["exact_top2_gap"] = dict(gap=gap, fp16_ulp=float(ulp16(abs(sx[order[0]] - 100.0))), near_tie=bool(near_tie))
+    assert h["top1_rank_in_exact"] == 0 or (near_tie and h["top1_rank_in_exact"] == 1), srep
 
 
 def test_tile_packed_conv_weights_are_the_same_convolution(dev):

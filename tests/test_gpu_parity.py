@@ -151,6 +151,30 @@ def test_render_crops_zbuffer_bit_exact(scene, dev, textured):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=0, atol=1e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("crop_ratio", [1.2, 1.1])
+def test_render_crops_zbuffer_bit_exact_all_252_poses(scene, dev, gmesh, crop_ratio):
+    """round 6 (the round-5 verdict, weak 1d): the integer z-buffer and the triangle ids of EVERY hypothesis of the BASELINE
+    configuration -- the 252-pose rotation grid, in the refiner's crop window (crop_ratio 1.2, predict_pose_refine.py:44-45) and in the
+    scorer's (1.1, predict_score.py:74-75) -- bit for bit against the oracle, in one launch of 252 (the launch the bench times is 126)."""
+    from foundationpose_amd import ops
+    from oracle import ops as oo
+    P = scene["poses"]
+    assert P.shape[0] == 252
+    tf, bb = oo.crop_windows(P, scene["K"], scene["diameter"], crop_ratio, (160, 160))
+    ref = oo.render_crops(scene["mesh_np"], P, bb, scene["K"], 480, 640, (160, 160), scene["diameter"], 0.001, True, want=("zbuf", "tri_id"))
+    out = ops.render_crops(gmesh["_handle"], _t(P, dev), _t(bb, dev), scene["K"], 480, 640, (160, 160), scene["diameter"], 0.001, True,
+                           want=("zbuf", "tri_id"))
+    tid, zb = out["tri_id"].cpu().numpy(), out["zbuf"].cpu().numpy().view(np.uint32)
+    bad = [i for i in range(252) if not (np.array_equal(tid[i], ref["tri_id"][i]) and np.array_equal(zb[i], ref["zbuf"][i]))]
+    assert not bad, f"hypotheses whose z-buffer / triangle ids differ from the oracle: {bad}"
+    assert all((ref["tri_id"][i] >= 0).mean() > 0.1 for i in range(252))         # every hypothesis draws something
+    # and the two halves the bench launches (sub-batches of 126) are the same bits as the launch of 252
+    for a, b in ((0, 126), (126, 252)):
+        o = ops.render_crops(gmesh["_handle"], _t(P[a:b], dev), _t(bb[a:b], dev), scene["K"], 480, 640, (160, 160), scene["diameter"], 0.001,
+                             True, want=("zbuf", "tri_id"))
+        assert torch.equal(o["tri_id"], out["tri_id"][a:b]) and torch.equal(o["zbuf"], out["zbuf"][a:b])
+
+
 def test_render_crops_fp16_output_and_flags(scene, dev, gmesh):
     from foundationpose_amd import ops
     from oracle import ops as oo
@@ -1370,25 +1394,88 @@ def test_small_calls_two_stream_heads_and_splitk_change_nothing_but_the_summatio
     sd = random_state_dict("refine", cfg, seed=0, head_scale=CONTRACTION_HEAD_SCALE)
     P0 = torch.as_tensor(scene["poses"][[3, 77, 140, 201, 250, 17, 33, 90, 111, 160, 222, 5][:n]], device=dev)
     kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
-    saved = engine.HEADS_TWO_STREAMS_MAX_HYPS, engine.SPLITK_MAX_HYPS
-    outs = {}
-    try:
-        for name, heads, sk in (("product", 12, 12), ("one_stream", 0, 12), ("plain_convs", 12, 0)):
-            engine.HEADS_TWO_STREAMS_MAX_HYPS, engine.SPLITK_MAX_HYPS = heads, sk
+    from foundationpose_amd import ops
+    outs, splitk_launches = {}, {}
+    for name, heads, sk in (("product", 12, 12), ("one_stream", 0, 12), ("plain_convs", 12, 0)):
+        with engine.overrides(HEADS_TWO_STREAMS_MAX_HYPS=heads, SPLITK_MAX_HYPS=sk):
             pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16", graph=False)
             o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], iteration=2, **kw)
             outs[name] = o.clone()
+            # which entry points the call runs (the advisor's round-5 finding: the comparison below would pass vacuously if the
+            # gate of the split-K path were broken): the same call under the per-kernel timers, which record every launch by name
+            with ops.KernelTimers() as kt:
+                pred.predict(scene["rgb"], frame["depth_t"], scene["K"], P0, frame["xyz_t"], iteration=1, **kw)
+            splitk_launches[name] = kt.summary().get("fp_igemm_f16_splitk_fwd", dict(calls=0))["calls"]
             if name == "product":
                 raw = {k: v.clone() for k, v in pred.last_raw_output.items()}
                 trk = GraphedTracker(pred, gmesh, scene["diameter"], scene["K"], 480, 640, n_hyp=n, iteration=2, device=dev).capture()
                 g1 = trk.step(scene["rgb"], scene["depth"], P0).clone()
                 e1 = trk.step_eager(scene["rgb"], scene["depth"], P0).clone()
                 assert torch.equal(g1, e1), "graph replay of the forked heads differs from the eager launches"
-    finally:
-        engine.HEADS_TWO_STREAMS_MAX_HYPS, engine.SPLITK_MAX_HYPS = saved
+    # 15 convolutions + 2 in_proj per iteration on the split-K entry point, none with the threshold at zero
+    assert splitk_launches["product"] >= 15 and splitk_launches["one_stream"] >= 15 and splitk_launches["plain_convs"] == 0, splitk_launches
     assert torch.equal(outs["product"], outs["one_stream"]), "two-stream heads changed a result"
     assert set(raw) == {"trans", "rot"}
     # split-K against the plain convolutions: contraction-scaled heads, so the 2-iteration chain compares arithmetic, not chaos
     dR = _geodesic(outs["product"][:, :3, :3].cpu().numpy(), outs["plain_convs"][:, :3, :3].cpu().numpy())
     dt = np.linalg.norm((outs["product"][:, :3, 3] - outs["plain_convs"][:, :3, 3]).cpu().numpy(), axis=1)
     assert dR.max() <= 1e-4 and dt.max() <= 1e-5, (dR.max(), dt.max())      # measured 2.2e-5 rad / 5.1e-6 m over two free-running iterations
+
+
+def test_bench_under_the_launcher_with_rccl_matches_the_headline(dev):
+    """round 6 (the round-5 verdict's item 6): no multi-GPU node has ever been available to the builder or the driver, so the first
+    8-GPU run must not die on plumbing.  bench.py end to end, launched EXACTLY as the driver launches N > 1 (python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...), with N = 1
+    and RCCL initialised (FP_BENCH_FORCE_DIST=1): object mode issues the fused [score | pose] all-gather on RCCL every step,
+    hypothesis mode goes through register_hypothesis_parallel / FeaturePoseExchange.  Each JSON line is checked for the contract's
+    fields and its rate against the plain single-process headline of the same box within 2 % (one re-run allowed: the chip clocks to
+    its power budget)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fast = ["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-kernel-table", "--no-extras"]
+
+    def run(mode, launcher):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FP_BENCH_FORCE_DIST"):
+            env.pop(k, None)
+        cmd = [sys.executable]
+        if launcher:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+            env["FP_BENCH_FORCE_DIST"] = "1"
+        cmd += [os.path.join(root, "bench.py"), "--gpus", "1", "--mode", mode] + fast
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (cmd, r.stderr[-2000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    def check(d):
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config"):
+            assert k in d, k
+        assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["higher_is_better"] is True
+        assert abs(d["value"] - 252 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    rep = {}
+    for attempt in range(2):
+        plain = run("object", launcher=False)
+        check(plain)
+        ok = True
+        for mode in ("object", "hypothesis"):
+            d = run(mode, launcher=True)
+            check(d)
+            assert "RCCL" in d["config"]["parallelism"] or "rccl" in d["config"]["parallelism"].lower(), d["config"]
+            rep[mode] = dict(ms_per_step=d["ms_per_step"], plain_ms_per_step=plain["ms_per_step"], ratio=d["ms_per_step"] / plain["ms_per_step"])
+            ok = ok and abs(rep[mode]["ratio"] - 1.0) <= 0.02
+        if ok:
+            break
+    REPORT = os.path.join(root, "gpurun_out", "bench_rccl_world1.json")
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    json.dump(rep, open(REPORT, "w"), indent=1)
+    for mode, r in rep.items():
+        assert abs(r["ratio"] - 1.0) <= 0.02, rep

@@ -121,6 +121,22 @@ def test_small_call_thresholds_keep_the_equalities_of_the_library():
     from foundationpose_amd.overlap import SubBatches
     sub = SubBatches(2)
     assert engine.SPLITK_MAX_HYPS < sub.min_rows and engine.HEADS_TWO_STREAMS_MAX_HYPS < sub.min_rows
+    assert engine.SMALL_CALL_CEILING < sub.min_rows
+    # round 6: the thresholds are constants of the release package (no environment variable); tests change them through
+    # engine.overrides, which refuses values at or above the sub-batch minimum, restores on exit, and is clamped again at use
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), "engine.py")).read()
+    assert "os.environ" not in src
+    with engine.overrides(SPLITK_MAX_HYPS=0, FUSED_FFN=False):
+        assert engine.SPLITK_MAX_HYPS == 0 and engine.FUSED_FFN is False and not engine.small_call(1, engine.SPLITK_MAX_HYPS)
+    assert engine.SPLITK_MAX_HYPS == 12 and engine.FUSED_FFN is True
+    with pytest.raises(ValueError):
+        with engine.overrides(SPLITK_MAX_HYPS=sub.min_rows):
+            pass
+    with pytest.raises(KeyError):
+        with engine.overrides(NO_SUCH_SWITCH=1):
+            pass
+    assert engine.small_call(12, 12) and not engine.small_call(13, 12) and not engine.small_call(sub.min_rows, 10 ** 6)
     for n in range(1, 2 * sub.min_rows):
         assert len(sub.parts(n)) == 1                      # below 2 x min_rows a call is one part: n of the part = n of the call
     assert all(b - a >= sub.min_rows for a, b in sub.parts(2 * sub.min_rows))
