@@ -62,9 +62,15 @@ def test_argument_errors_are_reported_without_gpu():
     assert lib.fp_pack_conv3x3_tiles_f16(C.c_void_p(16), C.c_void_p(16), 128, 64, None) == -1          # in place
     assert lib.fp_pack_conv3x3_tiles_f16(C.c_void_p(16), C.c_void_p(32), 100, 64, None) == -1 and b"multiple of 128" in lib.fp_last_error()
     ep = IgemmEpilogue()
-    ep.w_tiles = 32
+    ep.w_tiles, ep.flags = 32, 4                             # FP_IGEMM_HAS_W_TILES: the member is read
     assert lib.fp_igemm_f16_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, C.byref(ep), None) == -1
     assert b"w_tiles" in lib.fp_last_error()
+    # ... and the split-K entry point refuses it under ITS name instead of ignoring it (round 6; error strings carry the entry point)
+    G9 = (C.c_int * 10)(1600, 40, 42, 42, 1, 0, 512, 0, 0, 0)
+    assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G9, C.c_void_p(16), C.c_void_p(16), G9, 4, 128, 512, 9, C.byref(ep), 4, C.c_void_p(16), 1 << 24, None) == -1
+    assert b"fp_igemm_f16_splitk_fwd" in lib.fp_last_error() and b"w_tiles" in lib.fp_last_error()
+    assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 100, 512, 1, None, 4, C.c_void_p(16), 1 << 24, None) == -1
+    assert lib.fp_last_error().startswith(b"fp_igemm_f16_splitk_fwd: N=100")
     # split-K variant: workspace size, piece count and workspace checks come before any launch
     assert lib.fp_igemm_splitk_workspace_bytes(400, 512, 12) == 12 * 4 * 4 * 65536 and lib.fp_igemm_splitk_workspace_bytes(400, 100, 2) == 0
     assert lib.fp_igemm_f16_splitk_fwd(C.c_void_p(16), G, C.c_void_p(16), C.c_void_p(16), G, 4, 128, 512, 1, None, 0, C.c_void_p(16), 1 << 20, None) == -1
