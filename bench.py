@@ -226,7 +226,39 @@ def tracking_bench(dev, sc, refiner, seq, hyps, iters, latency_frames=200):
                 ls.append(time.perf_counter() - t0)
             lat[name] = {"median": float(np.median(ls) * 1e3), "p95": float(np.percentile(ls, 95) * 1e3)}
         assert torch.isfinite(out).all()
+        # round 6: the same loop as a two-slot pipeline (graphs.FramePipeline): upload + u8 -> f32 + erode + bilateral + back-projection
+        # of frame f + 1 on an ingest stream under the refine loop of frame f; frame f + 1's refine still waits for frame f's
+        from foundationpose_amd.graphs import FramePipeline
+        pipe = FramePipeline(trk)
+
+        def run_pipelined(n, sync_each=False, keep=0):
+            outs, ls = [], []
+            pipe.submit(0, rgb_h[0], depth_h[0], hyp_h[0])
+            for f in range(n):
+                t1 = time.perf_counter()
+                if f + 1 < n:
+                    pipe.submit((f + 1) % 2, rgb_h[f + 1], depth_h[f + 1], hyp_h[f + 1])
+                o = pipe.run(f % 2)
+                if f < keep:
+                    outs.append(o.clone())
+                if sync_each:
+                    torch.cuda.synchronize()
+                    ls.append(time.perf_counter() - t1)
+            torch.cuda.synchronize()
+            return outs, ls
+        run_pipelined(5)
+        t0 = time.perf_counter()
+        run_pipelined(F_)
+        res["pipelined"] = (time.perf_counter() - t0) / F_
+        _, ls = run_pipelined(min(F_, latency_frames), sync_each=True)
+        lat["pipelined"] = {"median": float(np.median(ls) * 1e3), "p95": float(np.percentile(ls, 95) * 1e3)}
+        keep = min(F_, 12)
+        po, _ = run_pipelined(keep, keep=keep)
+        same = all(bool(torch.equal(po[f], frame(f, True))) for f in range(keep))
     return {"frames": F_, "hypotheses_per_frame": hyps, "refine_iterations": iters, "distinct_frames": F_,
+            "pipelined_ms_per_frame": res["pipelined"] * 1e3, "frames_per_sec_pipelined": 1.0 / res["pipelined"],
+            "latency_ms_synced_per_frame_pipelined": lat["pipelined"], "pipelined_poses_equal_unpipelined": bool(same),
+            "ingest_stream_overlaps": pipe.ingest_overlaps,
             "uploads_per_frame_bytes": int(rgb_h[0].numel() + depth_h[0].numel() * 4 + hyp_h[0].numel() * 4),
             "hipgraph_ms_per_frame": res["hipgraph"] * 1e3, "eager_ms_per_frame": res["eager"] * 1e3,
             "frames_per_sec": 1.0 / res["hipgraph"], "frames_per_sec_eager": 1.0 / res["eager"],

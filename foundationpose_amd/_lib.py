@@ -39,7 +39,7 @@ SIGNATURES = {
     "fp_layernorm_res_fwd": (ci, [vp, vp, vp, ci, vp, vp, vp, cf, vp, vp, ci, ci, vp]),
     "fp_pack_linear512_f16": (ci, [vp, vp, vp]),
     "fp_linear512_f16_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
-    "fp_linear_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp, cf, vp, vp, ci, ci, ci, vp]),
+    "fp_linear_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp, cf, vp, vp, ci, ci, ci, ci, vp]),
     "fp_ffn_layernorm_mean_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp, C.c_size_t, ci, ci, vp]),
     "fp_colmean_f16_fwd": (ci, [vp, vp, vp, vp, cf, vp, ci, ci, ci, vp]),
     "fp_rows_linear_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),

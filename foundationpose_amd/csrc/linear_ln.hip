@@ -73,6 +73,7 @@ struct LinearLnParams {
   float* y32;             // either may be null
   _Float16* y16;
   int M;
+  int ldx;                // row stride of X in fp16 values (512 = dense; 1024: one head's half of a two-head attention output)
   float* part;            // MEAN form: chunk sums [M / 16][512] (16 consecutive rows each); S = rows per group
   const _Float16* W2p;    // FFN form: second Linear, fragment-packed, and its bias; Wp / bias are the first (+ ReLU)
   const float* bias2;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
     const int c = (lane % 4) ^ ll_swz(row);
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    aoff32 = (unsigned)(((size_t)m * LL_K + c * 8) * 2);
+    aoff32 = (unsigned)(((size_t)m * p.ldx + c * 8) * 2);
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.X), 0, 0x7FFFFFFF, 0x00020000);
   auto request_a = [&](int ks) { ll_dma16(rsA, smem + ks * LL_A_BLOCK + wid * 1024, (int)aoff32, ks * (LL_BK * 2)); };
@@ -429,7 +430,7 @@ struct Linear512Params {
 };
 constexpr int L5_XBUF = 32 * 64;                                   // a wave's transposition buffer: 32 rows x 32 channels fp16
 constexpr int L5_BIAS_OFF = LL_E_BYTES + LL_NW * L5_XBUF;          // bias vector (N floats) behind the eight buffers
-constexpr int L5_MAX_N = 2048;
+constexpr int L5_MAX_N = 3072;                                     // round 6: the in_proj of BOTH refiner heads in one launch (2 x 1536)
 constexpr int l5_lds(int N) { return L5_BIAS_OFF + N * 4; }
 static_assert(l5_lds(L5_MAX_N) <= 160 * 1024, "tile does not fit the 160 KiB LDS");
 
@@ -442,12 +443,13 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_linear512(Linear512Params p) 
   const int m0 = blockIdx.x * LL_BM;
   const int nblk = p.N / LL_BN;
 
-  // bias -> LDS: N / 256 pieces of 1 KiB, one LDS-DMA each (waves 0 .. N / 256 - 1; oldest vector-memory operation of the wave)
-  if (wid < p.N / 256) {
-    float* dst = bias_lds + wid * 256;
+  // bias -> LDS: N / 256 pieces of 1 KiB, one LDS-DMA each (piece q by wave q % 8; the oldest vector-memory operations of the wave, so
+  // every later counted wait covers them)
+  for (int q = wid; q < p.N / 256; q += LL_NW) {
+    float* dst = bias_lds + q * 256;
     if (p.bias) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
-      ll_dma16(rs, dst, lane * 16, wid * 1024);
+      ll_dma16(rs, dst, lane * 16, q * 1024);
     } else {
       *reinterpret_cast<float4_*>(dst + lane * 4) = float4_{0.f, 0.f, 0.f, 0.f};
     }
@@ -657,7 +659,7 @@ extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1_packed,
   FP_REQUIRE(workspace_bytes >= (size_t)(M / 16) * 512 * sizeof(float), "fp_ffn_layernorm_mean_fwd: workspace too small");
   LinearLnParams p;
   p.X = (const _Float16*)y16; p.Wp = (const _Float16*)w1_packed; p.bias = b1; p.x32 = x32; p.tok16 = nullptr; p.pe = nullptr;
-  p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M;
+  p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M; p.ldx = LL_K;
   p.part = workspace; p.W2p = (const _Float16*)w2_packed; p.bias2 = b2;
   FP_SET_MAX_LDS((k_rows512<true, true>), LL_LDS);
   hipLaunchKernelGGL((k_rows512<true, true>), dim3(tiles), dim3(LL_THREADS), LL_LDS, (hipStream_t)stream, p);
@@ -669,19 +671,21 @@ extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1_packed,
 
 extern "C" int fp_linear_layernorm_fwd(const void* x16, const void* w16_packed, const float* bias, const float* x32, const void* tok16,
                                        const float* pe, int S, const float* gamma, const float* beta, float eps, float* y32,
-                                       void* y16, int M, int K, int D, void* stream) {
+                                       void* y16, int M, int K, int D, int ldx, void* stream) {
   FP_REQUIRE(M >= 0, "fp_linear_layernorm_fwd: M < 0");
   if (M == 0) return FP_OK;
   FP_REQUIRE(x16 && w16_packed && gamma && beta && (y32 || y16), "fp_linear_layernorm_fwd: NULL tensor");
   FP_REQUIRE((x32 != nullptr) != (tok16 != nullptr), "fp_linear_layernorm_fwd: give the residual as x32 OR as tok16 (+ pe)");
   FP_REQUIRE(x32 || (pe && S > 0), "fp_linear_layernorm_fwd: tok16 needs the positional table and its period");
   FP_REQUIRE(D == 512 && K == 512, "fp_linear_layernorm_fwd: K=%d D=%d unsupported (d_model of both networks is 512; the A tile of 128 rows x K lives in LDS whole)", K, D);
-  FP_REQUIRE((long long)M * K < (1ll << 30), "fp_linear_layernorm_fwd: operands exceed 2 GiB");
+  if (ldx == 0) ldx = K;
+  FP_REQUIRE(ldx >= K && ldx % 8 == 0, "fp_linear_layernorm_fwd: ldx=%d must be a multiple of 8 and at least K", ldx);
+  FP_REQUIRE((long long)M * ldx < (1ll << 30), "fp_linear_layernorm_fwd: operands exceed 2 GiB");
   FP_REQUIRE((((size_t)x16 | (size_t)w16_packed | (size_t)bias | (size_t)x32 | (size_t)tok16 | (size_t)pe | (size_t)gamma | (size_t)beta |
                (size_t)y32 | (size_t)y16) & 15) == 0, "fp_linear_layernorm_fwd: tensors must be 16-byte aligned");
   LinearLnParams p;
   p.X = (const _Float16*)x16; p.Wp = (const _Float16*)w16_packed; p.bias = bias; p.x32 = x32; p.tok16 = (const _Float16*)tok16; p.pe = pe;
-  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.part = nullptr; p.W2p = nullptr; p.bias2 = nullptr;
+  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.ldx = ldx; p.part = nullptr; p.W2p = nullptr; p.bias2 = nullptr;
   FP_SET_MAX_LDS((k_rows512<false, false>), LL_LDS);
   hipLaunchKernelGGL((k_rows512<false, false>), dim3(fp_cdiv(M, LL_BM)), dim3(LL_THREADS), LL_LDS, (hipStream_t)stream, p);
   FP_CHECK_LAUNCH("fp_linear_layernorm_fwd");

@@ -70,6 +70,9 @@ ROWS_QKV_MIN_ROWS = 4096
 # round 5: the encoder's stride-1 3x3 convolutions hand fp_igemm_f16_fwd a tile-packed copy of their weights as well (epilogue.w_tiles): the
 # shifted-window kernel then stages a k-step's weight tile from one contiguous 8 KiB run.  Same operands, same order: the same bits.
 PACKED_CONV_TILES = True
+# round 6: RefineNet's trans_head and rot_head read the same tokens: their in_proj as one 3072-wide launch, their attention as one 8-head
+# launch (RefinePlan.__init__); the same bits as two calls each.  overrides(MERGED_HEAD_QKV=False) goes back to them.
+MERGED_HEAD_QKV = True
 
 
 def _conv_backend():
@@ -213,7 +216,7 @@ SPLITK_TARGET_WGS = 384        # (tile, piece) workgroups a launch should have: 
 # the hard ceiling of both thresholds: overlap.SubBatches' default min_rows (a call of >= 2 x 32 hypotheses is split into sub-batches)
 SMALL_CALL_CEILING = 31
 
-_SWITCHES = ("FUSED_OUT_PROJ_LN", "FUSED_FFN", "ROWS_QKV", "PACKED_CONV_TILES", "SPLITK_MAX_HYPS", "HEADS_TWO_STREAMS_MAX_HYPS")
+_SWITCHES = ("FUSED_OUT_PROJ_LN", "FUSED_FFN", "ROWS_QKV", "PACKED_CONV_TILES", "MERGED_HEAD_QKV", "SPLITK_MAX_HYPS", "HEADS_TWO_STREAMS_MAX_HYPS")
 
 
 @contextlib.contextmanager
@@ -431,12 +434,16 @@ class _HipEncoderLayer:
 
     def pooled(self, tok16, x16, pe, slot=0, small_calls=True):
         """-> mean over the tokens of the layer output, (N, 512) fp32"""
+        return self.pooled_from_context(self.att.context(x16, slot, small_calls), tok16, pe)
+
+    def pooled_from_context(self, ctx16, tok16, pe):
+        """the layer behind the attention context (heads merged, before out_proj): ctx16 (N, L, 512) fp16, possibly a column block of a
+        wider tensor (RefinePlan's two heads as one 8-head attention call)"""
         if FUSED_OUT_PROJ_LN:
             # out_proj + residual + norm1 in one launch, the projection staying on chip (fp_linear_layernorm_fwd): the same bits
-            y32, y16 = ops.linear_layernorm_res(self.att.context(x16, slot, small_calls), self.out_p, self.att.out.b, self.n1[0], self.n1[1], 1e-5,
-                                                tok16=tok16, pe=pe)
+            y32, y16 = ops.linear_layernorm_res(ctx16, self.out_p, self.att.out.b, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)
         else:
-            sa = self.att(x16, slot, small_calls)                                # fp16
+            sa = self.att.out(ctx16.contiguous())                                # fp16
             y32, y16 = ops.layernorm_res(sa, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)   # LN(x + sa): fp32 stream + fp16 copy
         if FUSED_FFN and y16.shape[1] % 16 == 0:
             return ops.ffn_layernorm_mean(y16, self.l1_p, self.l1.b, self.l2_p, self.l2.b, y32, self.n2[0], self.n2[1], 1e-5)
@@ -473,6 +480,17 @@ class RefinePlan:
             for name in ("trans", "rot"):
                 self.heads[name] = (_HipEncoderLayer(sd, f"{name}_head.0"),
                                     _HipRowsLinear(sd[f"{name}_head.1.weight"], sd[f"{name}_head.1.bias"]))
+            # round 6: the self-attention of the two heads as ONE in_proj launch (512 -> 3072, the token tile fetched once) and ONE
+            # 8-head attention launch.  Rows of the merged weight: [q_trans q_rot | k_trans k_rot | v_trans v_rot], i.e. the layout of an
+            # 8-head nn.MultiheadAttention whose heads 0-3 are trans_head's and 4-7 rot_head's (refine_network.py:56-70); per element the
+            # same dot products in the same order, so the same bits as the two separate calls (tests/test_gpu_parity.py)
+            wt, wr = (self.heads[n][0].att.qkv for n in ("trans", "rot"))
+            if tuple(wt.w.shape) == (1536, 512) and tuple(wr.w.shape) == (1536, 512):
+                cut = lambda t: (t[0:512], t[512:1024], t[1024:1536])
+                self.qkv2_p = ops.PackedLinear512(torch.cat([p for pair in zip(cut(wt.w), cut(wr.w)) for p in pair], 0).contiguous())
+                self.qkv2_b = torch.cat([p for pair in zip(cut(wt.b), cut(wr.b)) for p in pair], 0).contiguous()
+            else:
+                self.qkv2_p = None
         else:
             self.enc = _Encoder(sd, "encodeA", "encodeAB", self.dtype, channels_last)
             for name in ("trans", "rot"):
@@ -516,6 +534,14 @@ class RefinePlan:
             run = lambda name, hslot: self.heads[name][1](self.heads[name][0].pooled(tok16, x16, self.enc.pe, hslot, sc), round_f16=True)
             side = self._head_side_stream(tok16)
             if side is None:
+                n_seq, L = int(tok16.shape[0]), int(tok16.shape[1])
+                if MERGED_HEAD_QKV and self.qkv2_p is not None and ROWS_QKV and n_seq * L >= ROWS_QKV_MIN_ROWS and \
+                        not (sc and small_call(n_seq, SPLITK_MAX_HYPS)):
+                    ctx = ops.attention_f16(ops.linear512(x16, self.qkv2_p, self.qkv2_b), 8)         # (N, L, 1024) = [trans | rot]
+                    for i, name in enumerate(("trans", "rot")):
+                        layer, lin = self.heads[name]
+                        out[name] = lin(layer.pooled_from_context(ctx[..., 512 * i:512 * (i + 1)], tok16, self.enc.pe), round_f16=True)
+                    return out
                 for name in self.heads:
                     out[name] = run(name, slot)
                 return out

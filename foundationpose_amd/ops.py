@@ -433,7 +433,7 @@ def _packed(w, name, out_features=512):
 
 
 def linear512(x16, w_packed, bias, relu=False, out=None):
-    """f16(x16 @ W^T + bias) for x16 (..., 512) fp16 and a PackedLinear512 of W (512 n, 512), n <= 4 (fp_linear512_f16_fwd): the
+    """f16(x16 @ W^T + bias) for x16 (..., 512) fp16 and a PackedLinear512 of W (512 n, 512), n <= 6 (fp_linear512_f16_fwd): the
     input tile of a workgroup is fetched once for all n column blocks; the bits of igemm_f16 with taps = 1"""
     x = _dev(x16, torch.float16, "x16")
     w = _packed(w_packed, "linear512", None)
@@ -452,14 +452,27 @@ def linear512(x16, w_packed, bias, relu=False, out=None):
 def linear_layernorm_res(x16, w_packed, bias, gamma, beta, eps=1e-5, x32=None, tok16=None, pe=None, want32=True, want16=True):
     """layernorm_res(f16(x16 @ w^T + bias), ...) in ONE launch, the product staying on chip (fp_linear_layernorm_fwd).
     x16 (..., 512) fp16, w_packed = PackedLinear512 of the (512, 512) weight -> (y32 | None, y16 | None) of shape (..., 512);
-    bit-identical to the two-kernel path"""
-    x = _dev(x16, torch.float16, "x16")
+    bit-identical to the two-kernel path.  x16 may be a column block `wide[..., c:c + 512]` of a contiguous wider tensor (one head's
+    half of a two-head attention output): the kernel reads it with the wide row stride"""
     w = _packed(w_packed, "linear_layernorm_res")
-    K = int(x.shape[-1])
+    if not (torch.is_tensor(x16) and x16.is_cuda and x16.dtype == torch.float16):
+        raise _lib.FpAmdError("linear_layernorm_res: x16 must be a CUDA float16 tensor")
+    K = int(x16.shape[-1])
     D = 512
     if K != 512:
         raise _lib.FpAmdError(f"linear_layernorm_res: x16 (..., {K}), must be (..., 512)")
-    M = x.numel() // K
+    M = x16.numel() // K
+    if x16.is_contiguous():
+        x, ldx = x16, K
+    else:
+        # a column block of a contiguous (..., ldx) tensor: unit stride in the last dimension, every leading stride that of the wide tensor
+        ldx = int(x16.stride(-2)) if x16.dim() >= 2 else K
+        ok = x16.stride(-1) == 1 and ldx % 8 == 0 and ldx >= K and x16.storage_offset() % 8 == 0
+        for d in range(x16.dim() - 2, 0, -1):
+            ok = ok and x16.stride(d - 1) == x16.stride(d) * x16.shape[d]
+        if not ok:
+            raise _lib.FpAmdError("linear_layernorm_res: x16 must be contiguous or a column block of a contiguous tensor")
+        x = x16
     x32 = _dev(x32, torch.float32, "x32"); tok16 = _dev(tok16, torch.float16, "tok16"); pe = _dev(pe, torch.float32, "pe")
     S = int(pe.shape[-2]) if pe is not None else 0
     shape = tuple(x.shape[:-1]) + (D,)
@@ -467,7 +480,7 @@ def linear_layernorm_res(x16, w_packed, bias, gamma, beta, eps=1e-5, x32=None, t
     y16 = torch.empty(shape, dtype=torch.float16, device=x.device) if want16 else None
     st = _lib.lib().fp_linear_layernorm_fwd(_ptr(x), _ptr(w), _ptr(_dev(bias, torch.float32, "bias")), _ptr(x32), _ptr(tok16), _ptr(pe), S,
                                             _ptr(_dev(gamma, torch.float32, "gamma")), _ptr(_dev(beta, torch.float32, "beta")), float(eps),
-                                            _ptr(y32), _ptr(y16), M, K, D, _stream(x))
+                                            _ptr(y32), _ptr(y16), M, K, D, ldx, _stream(x))
     _lib.check(st, "fp_linear_layernorm_fwd")
     return y32, y16
 

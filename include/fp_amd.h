@@ -63,7 +63,8 @@ const char* fp_last_error(void);
  *   210 -> 211 (round 5): + fp_igemm_f16_splitk_fwd / fp_igemm_splitk_workspace_bytes (additions only).
  *   211 -> 212 (round 5): fp_igemm_epilogue grew by one member at its end (w_tiles); + fp_pack_conv3x3_tiles_f16.
  *   212 -> 213 (round 6): w_tiles is read only when flags has FP_IGEMM_HAS_W_TILES (a 212 caller that sets w_tiles without the bit
- *                         gets the plain weight path: correct, slower); fp_igemm_f16_splitk_fwd refuses w_tiles instead of ignoring it. */
+ *                         gets the plain weight path: correct, slower); fp_igemm_f16_splitk_fwd refuses w_tiles instead of ignoring it;
+ *                         fp_linear_layernorm_fwd takes the row stride of x16 (new argument before the stream). */
 #define FP_AMD_ABI_VERSION 213
 int fp_version(void);
 
@@ -234,7 +235,7 @@ int fp_layernorm_res_fwd(const float* x32 /*dev|NULL*/, const void* tok16 /*dev|
 int fp_pack_linear512_f16(const void* w16 /*dev*/, void* packed /*dev*/, void* stream);
 
 /* y16 (M, N) = f16(x16 (M, 512) @ W^T + bias) [ReLU if relu != 0]: nn.Linear under autocast (fp16 operands, fp32 accumulation +
- * bias, one rounding) for in_features = 512 and N = 512 n <= 2048 output features -- the in_proj of nn.MultiheadAttention (N = 1536;
+ * bias, one rounding) for in_features = 512 and N = 512 n <= 3072 output features -- the in_proj of nn.MultiheadAttention (N = 1536;
  * refine_network.py:56-70 through nn.TransformerEncoderLayer, score_network.py:52-53,73,86).  The bits of fp_igemm_f16_fwd with
  * taps = 1 (same k order per accumulator); a workgroup fetches its 128 x 512 input tile once and keeps it in LDS for all N / 512
  * column blocks, weights from L2 into registers.  w_packed: the N / 512 blocks of 512 output channels of W (N, 512), each through
@@ -247,11 +248,14 @@ int fp_linear512_f16_fwd(const void* x16 /*dev*/, const void* w_packed /*dev*/, 
  * fp_igemm_f16_fwd (taps = 1, N = 512) followed by fp_layernorm_res_fwd with branch16 = that product, in one launch and
  * without the (M, 512) product reaching HBM; per element the same instruction sequence, i.e. the same bits.
  * x16 (M, 512) fp16, w16_packed = fp_pack_linear512_f16 of the (512, 512) weight, bias (512) f32 | NULL; K and D must be 512 (the
- * 128 x K A tile of a workgroup lives in LDS whole); the other arguments as fp_layernorm_res_fwd. */
+ * 128 x K A tile of a workgroup lives in LDS whole); the other arguments as fp_layernorm_res_fwd.  ldx (ABI 213): x16 may be a column
+ * block of a wider matrix -- one head's (M, 512) half of the (M, 1024) output of a two-head fp_attention_f16_fwd call (round 6: the
+ * self-attention of RefineNet's trans_head and rot_head, refine_network.py:56-70, as one 8-head launch). */
 int fp_linear_layernorm_fwd(const void* x16 /*dev*/, const void* w16_packed /*dev*/, const float* bias /*dev|NULL*/,
                             const float* x32 /*dev|NULL*/, const void* tok16 /*dev|NULL*/, const float* pe /*dev|NULL*/, int S,
                             const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps, float* y32 /*dev|NULL*/,
-                            void* y16 /*dev|NULL*/, int M, int K, int D, void* stream);
+                            void* y16 /*dev|NULL*/, int M, int K, int D, int ldx /* row stride of x16 in fp16 values; 0 = K */,
+                            void* stream);
 
 /* The feed-forward half of nn.TransformerEncoderLayer (refine_network.py:56-70: linear1 -> ReLU -> linear2, `x + ff`, norm2; under
  * autocast: fp16 Linears with fp32 accumulation + bias and one rounding each, fp32 residual stream and LayerNorm) fused with the

@@ -85,7 +85,7 @@ def test_argument_errors_are_reported_without_gpu():
                                     C.c_void_p(16), None, 4, 512, None) == -1     # residual given twice
     assert lib.fp_attention_f16_fwd(C.c_void_p(16), C.c_void_p(16), 1, 4, 4, 128, 2, None) == -1
     assert lib.fp_linear_layernorm_fwd(C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16),
-                                       C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 256, 512, None) == -1         # K != 512
+                                       C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 256, 512, 0, None) == -1      # K != 512
     assert b"K=256" in lib.fp_last_error()
     assert lib.fp_pack_linear512_f16(C.c_void_p(16), C.c_void_p(16), None) == -1                                   # in place
     assert lib.fp_pack_linear512_f16(None, C.c_void_p(16), None) == -1
@@ -93,7 +93,11 @@ def test_argument_errors_are_reported_without_gpu():
     assert b"multiple of 512" in lib.fp_last_error()
     assert lib.fp_linear512_f16_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), 0, 1536, 0, None) == 0        # nothing to do
     assert lib.fp_linear_layernorm_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 400,
-                                       C.c_void_p(16), C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 512, 512, None) == -1   # residual twice
+                                       C.c_void_p(16), C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 512, 512, 0, None) == -1   # residual twice
+    assert lib.fp_linear_layernorm_fwd(C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), C.c_void_p(16), 400, C.c_void_p(16),
+                                       C.c_void_p(16), 1e-5, C.c_void_p(16), None, 4, 512, 512, 500, None) == -1    # row stride below K
+    assert b"ldx=500" in lib.fp_last_error()
+    assert lib.fp_linear512_f16_fwd(C.c_void_p(16), C.c_void_p(16), None, C.c_void_p(16), 4, 3584, 0, None) == -1       # N > 3072
     assert lib.fp_replicate_rows_f16(C.c_void_p(16), C.c_void_p(32), 3, 10, 100, 256, 256, 2560, None) == -1      # 100 channels
     assert b"multiples of 8" in lib.fp_last_error()
     assert lib.fp_replicate_rows_f16(C.c_void_p(16), C.c_void_p(32), 3, 10, 128, 64, 256, 2560, None) == -1       # stride < channels

@@ -544,6 +544,48 @@ def test_graphed_tracker_replays_the_eager_result(scene, dev, gmesh, frame):
     assert torch.equal(b, c)
 
 
+@pytest.mark.parametrize("n_hyp", [1, 64])
+def test_frame_pipeline_returns_the_bits_of_the_unpipelined_loop(scene, dev, gmesh, n_hyp):
+    """round 6, BASELINE configs[4] as its own workload (graphs.FramePipeline): upload + u8 -> f32 + depth filters + back-projection of
+    frame f + 1 on an ingest stream under the refine loop of frame f, two staging slots handed over with events.  Twelve distinct
+    frames (own noise, own depth, own hypotheses): every frame's poses equal GraphedTracker.step on the same host data bit for bit,
+    with uploaded hypotheses and in tracking mode (the previous output is the next start: never uploaded)."""
+    from foundationpose_amd import synthetic as syn
+    from foundationpose_amd.graphs import FramePipeline, GraphedTracker
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import CONTRACTION_HEAD_SCALE, DEFAULT_REFINE_CFG, random_state_dict
+    refiner = PoseRefinePredictor(cfg=dict(DEFAULT_REFINE_CFG), state_dict=random_state_dict("refine", seed=0, head_scale=CONTRACTION_HEAD_SCALE),
+                                  device=dev)
+    F = 12
+    rng = np.random.default_rng(5)
+    rgb_h = torch.empty((F, 480, 640, 3), dtype=torch.uint8).pin_memory()
+    depth_h = torch.empty((F, 480, 640), dtype=torch.float32).pin_memory()
+    hyp_h = torch.empty((F, n_hyp, 4, 4), dtype=torch.float32).pin_memory()
+    for f in range(F):
+        rgb_h[f].copy_(torch.from_numpy(np.clip(scene["rgb"].astype(np.float32) + rng.normal(0, 4, scene["rgb"].shape), 0, 255).astype(np.uint8)))
+        depth_h[f].copy_(torch.from_numpy((scene["depth"] + 0.0005 * f).astype(np.float32)))
+        hyp_h[f].copy_(torch.from_numpy(syn.perturbed_poses(scene["gt"], n_hyp, seed=50 + f, max_trans=0.02, max_rot_deg=10.0).astype(np.float32)))
+    trk = GraphedTracker(refiner, gmesh, scene["diameter"], scene["K"], 480, 640, n_hyp=n_hyp, iteration=2, device=dev).capture()
+    ref = [trk.step(rgb_h[f].to(dev).float(), depth_h[f], hyp_h[f]).clone() for f in range(F)]
+    trk._have_output = False
+    ref_track = [trk.step(rgb_h[0].to(dev).float(), depth_h[0], hyp_h[0]).clone()]
+    for f in range(1, F):
+        ref_track.append(trk.step(rgb_h[f].to(dev).float(), depth_h[f]).clone())
+    pipe = FramePipeline(trk)
+    for mode, want in (("uploaded", ref), ("tracking", ref_track)):
+        trk._have_output = False
+        got = []
+        pipe.submit(0, rgb_h[0], depth_h[0], hyp_h[0])
+        for f in range(F):
+            if f + 1 < F:
+                pipe.submit((f + 1) % 2, rgb_h[f + 1], depth_h[f + 1], hyp_h[f + 1] if mode == "uploaded" else None)
+            got.append(pipe.run(f % 2).clone())
+        torch.cuda.synchronize()
+        bad = [f for f in range(F) if not torch.equal(got[f], want[f])]
+        assert not bad, (mode, bad)
+    assert not torch.equal(ref[3], ref[4]) and not torch.equal(ref_track[3], ref_track[4])      # the frames differ
+
+
 def test_sub_batches_on_concurrent_streams_change_nothing(scene, dev, gmesh, frame):
     """overlap.py: the refiner's / scorer's hypothesis sub-batches on two streams give the bits of one batch on one stream
     (same kernels and summation order per hypothesis), eagerly and inside a captured graph"""
@@ -672,7 +714,7 @@ def test_linear512_is_the_igemm_linear(dev):
     from foundationpose_amd import ops
     from foundationpose_amd.engine import _HipLinear
     g = torch.Generator(device="cpu").manual_seed(21)
-    for N in (1536, 512, 2048):
+    for N in (1536, 512, 2048, 3072):            # 3072 (round 6): the in_proj of both refiner heads in one launch, 12 bias pieces on 8 waves
         lin = _HipLinear((torch.randn((N, 512), generator=g) * 0.05).to(dev), (torch.randn((N,), generator=g) * 0.1).to(dev))
         wp = ops.PackedLinear512(lin.w)
         for M in (126 * 400, 3 * 400, 129, 1):
@@ -687,6 +729,55 @@ def test_linear512_is_the_igemm_linear(dev):
         assert torch.equal(nob, _HipLinear(lin.w, torch.zeros(N, device=dev))(x))
     with pytest.raises(Exception):
         ops.linear512(torch.zeros((4, 256), dtype=torch.float16, device=dev), wp, None)
+
+
+def test_merged_head_attention_is_the_two_separate_heads(scene, dev, gmesh, frame):
+    """round 6 (the round-5 verdict's item 2): RefineNet's trans_head and rot_head as ONE in_proj launch (512 -> 3072) + ONE 8-head
+    attention launch, out_proj + LayerNorm reading its head's half of the (N, 400, 1024) context through the row stride: (i) the strided
+    fp_linear_layernorm_fwd returns the bits of the dense call on a copy of the column block; (ii) the whole plan with the switch on
+    returns the bits of the plan with the switch off (raw network outputs of 126 and 40 hypotheses, both residual forms exercised)."""
+    from foundationpose_amd import engine, ops
+    from foundationpose_amd.refine_network import RefineNet
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, random_state_dict
+    g = torch.Generator(device="cpu").manual_seed(33)
+    wide = (torch.randn((7, 400, 1024), generator=g) * 0.5).half().to(dev)
+    w = ops.PackedLinear512((torch.randn((512, 512), generator=g) * 0.05).half().to(dev))
+    b = (torch.randn(512, generator=g) * 0.1).half().float().to(dev)
+    gm, bt = (torch.rand(512, generator=g) + 0.5).to(dev), (torch.randn(512, generator=g) * 0.1).to(dev)
+    tok = (torch.randn((7, 400, 512), generator=g)).half().to(dev)
+    pe = torch.randn((400, 512), generator=g).to(dev)
+    x32 = torch.randn((7, 400, 512), generator=g).to(dev)
+    for c in (0, 512):
+        blk = wide[..., c:c + 512]
+        assert not blk.is_contiguous()
+        for kw in (dict(tok16=tok, pe=pe), dict(x32=x32)):
+            a32, a16 = ops.linear_layernorm_res(blk, w, b, gm, bt, 1e-5, **kw)
+            d32, d16 = ops.linear_layernorm_res(blk.contiguous(), w, b, gm, bt, 1e-5, **kw)
+            assert torch.equal(a32, d32) and torch.equal(a16, d16), c
+    with pytest.raises(Exception):
+        ops.linear_layernorm_res(wide[..., 4:516], w, b, gm, bt, 1e-5, x32=x32)          # misaligned column block
+    with pytest.raises(Exception):
+        ops.linear_layernorm_res(wide[:, ::2, :512], w, b, gm, bt, 1e-5, x32=x32[:, ::2])  # not a column block
+    cfg = dict(DEFAULT_REFINE_CFG)
+    net = RefineNet(cfg=cfg, c_in=6)
+    net.load_state_dict(random_state_dict("refine", cfg, seed=0))
+    plan = engine.RefinePlan(net, dev, precision="fp16")
+    assert plan.qkv2_p is not None and plan.qkv2_p.out_features == 3072
+    from oracle import pipeline as op
+    for n in (126, 40):
+        A, B, _, _ = op.refine_inputs(cfg, scene["poses"][:n], scene["mesh_np"], scene["rgb"], frame["xyz"], scene["K"], scene["diameter"])
+        AB = torch.cat([torch.from_numpy(A), torch.from_numpy(B)]).half().to(dev)
+        outs = {}
+        for on in (True, False):
+            with engine.overrides(MERGED_HEAD_QKV=on):
+                with ops.KernelTimers() as kt:
+                    o = plan(AB)
+                calls = {k: v["calls"] for k, v in kt.summary().items()}
+                assert calls["fp_attention_f16_fwd"] == (1 if on else 2) and calls["fp_linear512_f16_fwd"] == (1 if on else 2), (on, calls)
+                outs[on] = plan(AB)
+        for k in ("trans", "rot"):
+            assert torch.equal(outs[True][k], outs[False][k]), (n, k)
+            assert float(outs[True][k].abs().max()) > 0
 
 
 def test_ffn_layernorm_mean_is_the_three_kernel_path_up_to_summation_order(dev):
