@@ -387,6 +387,9 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+_AB_OVERRIDES = []
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -451,7 +454,8 @@ def main():
     ab = os.environ.get("FP_BENCH_ENGINE", "").strip()
     if ab:
         from foundationpose_amd import engine
-        engine.overrides(**{k.strip(): int(v) for k, v in (kv.split("=") for kv in ab.split(","))}).__enter__()
+        _AB_OVERRIDES.append(engine.overrides(**{k.strip(): int(v) for k, v in (kv.split("=") for kv in ab.split(","))}))
+        _AB_OVERRIDES[-1].__enter__()          # kept alive for the life of the process: a collected generator would restore the switches
     N, R = args.hyps, args.refine_iters
     hyp_mode = args.mode == "hypothesis"
     _log("building scene")

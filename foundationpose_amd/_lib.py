@@ -41,6 +41,8 @@ SIGNATURES = {
     "fp_linear512_f16_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
     "fp_linear_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, vp, cf, vp, vp, ci, ci, ci, ci, vp]),
     "fp_ffn_layernorm_mean_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp, C.c_size_t, ci, ci, vp]),
+    "fp_encoder_tail_workspace_bytes": (sz, [ci, ci]),
+    "fp_encoder_tail_mean_fwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp, sz, ci, ci, vp]),
     "fp_colmean_f16_fwd": (ci, [vp, vp, vp, vp, cf, vp, ci, ci, ci, vp]),
     "fp_rows_linear_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "fp_attention_f16_fwd": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),

@@ -77,6 +77,8 @@ struct LinearLnParams {
   float* part;            // MEAN form: chunk sums [M / 16][512] (16 consecutive rows each); S = rows per group
   const _Float16* W2p;    // FFN form: second Linear, fragment-packed, and its bias; Wp / bias are the first (+ ReLU)
   const float* bias2;
+  const _Float16* W1p;    // TAIL form: Wp / bias = out_proj, W1p / bias1 = linear1 (+ ReLU), W2p / bias2 = linear2; gamma / beta = norm1's
+  const float* bias1;     //   (norm2's are applied by k_ln_mean_finish); y32 = scratch for norm1's fp32 output (the second residual)
 };
 
 // Fragment-packed weight matrix: for channel group w (64 output channels = one wave), k16-step q, channel tile i (32 channels), the
@@ -134,8 +136,14 @@ __device__ __forceinline__ constexpr int ll_after_w(int k1) {
 // order and writes the chunk sum; k_ln_mean_finish adds a hypothesis's S / 16 chunk sums in chunk order.
 // FFN: TWO Linears back to back on the tile, linear1 + ReLU -> the 128 x 512 intermediate parked in the epilogue tile -> linear2
 // reading its A fragments from that tile (no barrier in the second loop).
-template <bool MEAN, bool FFN>
+// TAIL (round 6, fp_encoder_tail_mean_fwd): everything of the encoder layer behind the attention context in ONE launch -- out_proj
+// (first loop, A tile by LDS-DMA) -> park -> norm1's row code (fp32 result to the scratch p.y32, its fp16 rounding IN PLACE into the
+// epilogue tile) -> linear1 out of that tile -> the FFN form's park / linear2 / park -> norm2's row code on y32 + token-mean chunk
+// sums.  Per element the instruction sequences of k_rows512<false, false> followed by k_rows512<true, true>: the same bits; what is
+// gone is the (M, 512) fp16 tensor between them (written + read), one launch and one cold start per layer.
+template <bool MEAN, bool FFN, bool TAIL = false>
 __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
+  static_assert(!TAIL || (MEAN && FFN), "the tail form ends in the FFN + token-mean form");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = channel group of 64
@@ -242,13 +250,13 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
   float rs[LL_R][8];
   // tile row of the wave's (t0 + u)-th row: interleaved (wave w: rows w, w + 8, ...) or, for the MEAN forms, one contiguous chunk
   auto tile_row = [&](int k) { return MEAN ? wid * LL_ROWS_PER_WAVE + k : wid + LL_NW * k; };
-  auto request_resid = [&](int t0) {
+  auto request_resid = [&](int t0, const float* x32) {
 #pragma unroll
     for (int u = 0; u < LL_R; ++u) {
       const int m = m0 + tile_row(t0 + u);
       const int mc = m < p.M ? m : p.M - 1;
-      if (p.x32) {
-        load8f(p.x32 + (size_t)mc * 512 + lane * 8, rs[u]);
+      if (x32) {
+        load8f(x32 + (size_t)mc * 512 + lane * 8, rs[u]);
       } else {
         tk[u] = *reinterpret_cast<const half8*>(p.tok16 + (size_t)mc * 512 + lane * 8);
         load8f(p.pe + (size_t)((unsigned)mc % (unsigned)p.S) * 512 + lane * 8, rs[u]);
@@ -257,66 +265,42 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
   };
   // requested before the accumulators are parked (in flight under the transposition) where the registers allow it
   constexpr bool EARLY_RESID = !FFN;   // FFN: the second loop needs the registers
-  if constexpr (EARLY_RESID) request_resid(0);
+  const float* const resid32 = TAIL ? p.y32 : p.x32;       // the residual of the LAST row code (TAIL: norm1's output, written below)
+  if constexpr (EARLY_RESID) request_resid(0, resid32);
 
   // ---- epilogue 1: f16(acc + bias) -> E[row][channel], rows of 1 KiB, the low 4 bits of the 16-byte chunk index XORed with
   // (row & 15) (igemm_epilogue.h).  D[i = channel][j = row]: a lane holds row (lane & 31) of a row tile and channels
   // 8 g + 4 (lane >> 5) + {0..3} of a channel tile, g = register >> 2
   unsigned char* E = smem;
   LL_CLK(t_pre);
-  if constexpr (FFN) {
-    // ---- linear1 done: H = relu(f16(acc + b1)) -> E, then linear2 out of E
-    {
-    #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-    #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = wid * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
-          const float4_ bv = *reinterpret_cast<const float4_*>(bias_lds + nl);
-    #pragma unroll
-          for (int j = 0; j < LL_TM; ++j) {
-            const int ml = j * 32 + (lane & 31);
-            half4 v;
-    #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
-            v = __builtin_elementwise_max(v, half4{0, 0, 0, 0});                   // ReLU of linear1
-            const int chunk = (nl >> 3) ^ (ml & 15);
-            *reinterpret_cast<half4*>(E + ml * (2 * LL_BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
-          }
-        }
-      }
-    }
-    __syncthreads();                 // H complete; nobody reads b1 any more
-    if (wid < 2) {                   // b2 -> the bias area (visible after the barrier that ends the second loop)
-      float* dst = bias_lds + wid * 256;
-      if (p.bias2) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias2), 0, LL_BN * 4, 0x00020000);
-        ll_dma16(rs, dst, lane * 16, wid * 1024);
-      } else {
-        *reinterpret_cast<float4_*>(dst + lane * 4) = float4_{0.f, 0.f, 0.f, 0.f};
-      }
-    }
+  // A fragments out of the epilogue tile E (k16-step q, row tile j: row 32 j + (lane & 31), logical chunk 2 q + (lane >> 5)) and a whole
+  // 512-deep product from it: weight fragments as in the first loop; nothing is shared between waves: no barrier inside
+  // (the row offset goes through an empty asm per product: with two products in one kernel -- the TAIL form -- hipcc otherwise keeps the
+  // 32 swizzled fragment addresses of the first alive for the second and spills ~110 registers around the MFMA loops)
+  unsigned erow_off = (unsigned)(frow * (2 * LL_BN));
+  int esw = frow & 15, efh = fhalf;
+  auto read_e = [&](int q, int slot) {
+    const unsigned char* erow = E + erow_off;
+#pragma unroll
+    for (int j = 0; j < LL_TM; ++j)
+      fa[slot][j] = *reinterpret_cast<const half8*>(erow + j * 32 * (2 * LL_BN) + (((2 * q + efh) ^ esw) << 4));
+  };
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < LL_TM; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // ---- second loop: H @ W2p^T.  A fragments of k16-step q, row tile j: row 32 j + (lane & 31) of E, logical chunk
-    // 2 q + (lane >> 5); weight fragments as in the first loop; nothing is shared between waves any more: no barrier
-    const unsigned char* erow = E + frow * (2 * LL_BN);
-    const int esw = frow & 15;
-    auto read_e = [&](int q, int slot) {
+  };
+  auto product_from_e = [&](const _Float16* wp) {
+    asm volatile("" : "+v"(erow_off), "+v"(esw), "+v"(efh));
 #pragma unroll
-      for (int j = 0; j < LL_TM; ++j)
-        fa[slot][j] = *reinterpret_cast<const half8*>(erow + j * 32 * (2 * LL_BN) + (((2 * q + fhalf) ^ esw) << 4));
-    };
-#pragma unroll
-    for (int j = 0; j < LL_LW; ++j) request_w(p.W2p, j, j);
+    for (int j = 0; j < LL_LW; ++j) request_w(wp, j, j);
     read_e(0, 0);
 #pragma unroll
     for (int ks = 0; ks < LL_NK; ++ks) {
-      if (ks + LL_LW < LL_NK) request_w(p.W2p, ks + LL_LW, (ks + LL_LW) % (LL_LW + 1));
+      if (ks + LL_LW < LL_NK) request_w(wp, ks + LL_LW, (ks + LL_LW) % (LL_LW + 1));
       read_e(2 * ks + 1, 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma_group(ks % (LL_LW + 1), 0, 0);
@@ -326,30 +310,101 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
       mfma_group(ks % (LL_LW + 1), 1, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  // f16(acc + bias) [ReLU] -> E[row][channel]
+  auto park = [&](auto relu_c) {
+    constexpr bool RELU = decltype(relu_c)::value;
+    int lane_p = lane;                       // opaque per call: the store addresses of one park are not kept (spilled) for the next
+    asm volatile("" : "+v"(lane_p));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wid * 64 + i * 32 + 8 * g + 4 * (lane_p >> 5);
+        const float4_ bv = *reinterpret_cast<const float4_*>(bias_lds + nl);
+#pragma unroll
+        for (int j = 0; j < LL_TM; ++j) {
+          const int ml = j * 32 + (lane_p & 31);
+          half4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
+          if constexpr (RELU) v = __builtin_elementwise_max(v, half4{0, 0, 0, 0});
+          const int chunk = (nl >> 3) ^ (ml & 15);
+          *reinterpret_cast<half4*>(E + ml * (2 * LL_BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
+        }
+      }
+    }
+  };
+  auto load_bias = [&](const float* b) {   // (512) -> the bias area; waves 0 and 1, visible after the next s_waitcnt vmcnt(0) + barrier
+    if (wid < 2) {
+      float* dst = bias_lds + wid * 256;
+      if (b) {
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, LL_BN * 4, 0x00020000);
+        ll_dma16(rs_, dst, lane * 16, wid * 1024);
+      } else {
+        *reinterpret_cast<float4_*>(dst + lane * 4) = float4_{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  if constexpr (TAIL) {
+    // ---- out_proj done: branch = f16(acc + bo) -> E, then k_layernorm_res512's row code (norm1) on the tile's rows: the fp32 result
+    // goes to the scratch, its fp16 rounding takes the branch's place in E -- the A operand of linear1
+    request_resid(0, nullptr);           // tok16 + pe rows, in flight under the transposition
+    park(std::false_type{});
+    __syncthreads();
+    {
+      float gm1[8], bt1[8];
+      load8f(p.gamma + lane * 8, gm1);
+      load8f(p.beta + lane * 8, bt1);
+#pragma unroll 1
+      for (int t0 = 0; t0 < LL_ROWS_PER_WAVE; t0 += LL_R) {
+        float f[LL_R][8];
+#pragma unroll
+        for (int u = 0; u < LL_R; ++u) {
+          const int r = tile_row(t0 + u);
+          const half8 b = *reinterpret_cast<const half8*>(E + r * (2 * LL_BN) + ((lane ^ (r & 15)) << 4));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            f[u][e] = (float)tk[u][e] + rs[u][e];             // resid_row (rowops_ln.h)
+            f[u][e] += (float)b[e];
+          }
+        }
+        if (t0 + LL_R < LL_ROWS_PER_WAVE) request_resid(t0 + LL_R, nullptr);
+        ln_rows<LL_R>(p.eps, f);
+#pragma unroll
+        for (int u = 0; u < LL_R; ++u) {
+          const int r = tile_row(t0 + u);
+          const int m = m0 + r;
+          half8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { f[u][e] = fmaf(f[u][e], gm1[e], bt1[e]); h[e] = (_Float16)f[u][e]; }
+          if (m < p.M) store8f(p.y32 + (size_t)m * 512 + lane * 8, f[u]);        // wave-uniform
+          *reinterpret_cast<half8*>(E + r * (2 * LL_BN) + ((lane ^ (r & 15)) << 4)) = h;
+        }
+      }
+    }
+    __syncthreads();                 // norm1's fp16 output is complete in E (every wave reads all rows); nobody reads bo any more
+    load_bias(p.bias1);
+    zero_acc();
+    product_from_e(p.W1p);           // linear1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // b1 has landed (waves 0, 1); this wave's y32 stores are out
+    __syncthreads();                 // every wave is done reading norm1's output before H takes its place
+  }
+  if constexpr (FFN) {
+    // ---- linear1 done: H = relu(f16(acc + b1)) -> E, then linear2 out of E
+    park(std::true_type{});
+    __syncthreads();                 // H complete; nobody reads b1 any more
+    load_bias(p.bias2);              // b2 -> the bias area (visible after the barrier that ends the second loop)
+    zero_acc();
+    product_from_e(p.W2p);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // b2 has landed (waves 0, 1)
     __syncthreads();                 // every wave is done reading H before linear2's output takes its place
   }
   LL_CLK(t_loop2);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = wid * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
-      const float4_ bv = *reinterpret_cast<const float4_*>(bias_lds + nl);
-#pragma unroll
-      for (int j = 0; j < LL_TM; ++j) {
-        const int ml = j * 32 + (lane & 31);
-        half4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (_Float16)(acc[i][j][g * 4 + e] + bv[e]);
-        const int chunk = (nl >> 3) ^ (ml & 15);
-        *reinterpret_cast<half4*>(E + ml * (2 * LL_BN) + (chunk << 4) + ((nl & 4) << 1)) = v;
-      }
-    }
-  }
+  park(std::false_type{});
   __syncthreads();
   LL_CLK(t_park);
-  if constexpr (!EARLY_RESID) request_resid(0);
+  if constexpr (!EARLY_RESID) request_resid(0, resid32);
 
   // ---- epilogue 2: k_layernorm_res512's row code on the tile's rows (wave w: rows w, w + 8, ...), LL_R rows at a time.
   // The residual rows of the NEXT group are requested before the current group is normalised (and those of the first group
@@ -372,11 +427,11 @@ __global__ __launch_bounds__(LL_THREADS, 1) void k_rows512(LinearLnParams p) {
       const half8 b = *reinterpret_cast<const half8*>(E + r * (2 * LL_BN) + ((lane ^ (r & 15)) << 4));
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        f[u][e] = p.x32 ? rs[u][e] : (float)tk[u][e] + rs[u][e];     // resid_row (rowops_ln.h)
+        f[u][e] = resid32 ? rs[u][e] : (float)tk[u][e] + rs[u][e];     // resid_row (rowops_ln.h)
         f[u][e] += (float)b[e];
       }
     }
-    if (t0 + LL_R < LL_ROWS_PER_WAVE) request_resid(t0 + LL_R);
+    if (t0 + LL_R < LL_ROWS_PER_WAVE) request_resid(t0 + LL_R, resid32);
     ln_rows<LL_R>(p.eps, f);
     if constexpr (MEAN) {
 #pragma unroll
@@ -660,12 +715,56 @@ extern "C" int fp_ffn_layernorm_mean_fwd(const void* y16, const void* w1_packed,
   LinearLnParams p;
   p.X = (const _Float16*)y16; p.Wp = (const _Float16*)w1_packed; p.bias = b1; p.x32 = x32; p.tok16 = nullptr; p.pe = nullptr;
   p.S = rows_per_group; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = nullptr; p.y16 = nullptr; p.M = (int)M; p.ldx = LL_K;
-  p.part = workspace; p.W2p = (const _Float16*)w2_packed; p.bias2 = b2;
+  p.part = workspace; p.W2p = (const _Float16*)w2_packed; p.bias2 = b2; p.W1p = nullptr; p.bias1 = nullptr;
   FP_SET_MAX_LDS((k_rows512<true, true>), LL_LDS);
   hipLaunchKernelGGL((k_rows512<true, true>), dim3(tiles), dim3(LL_THREADS), LL_LDS, (hipStream_t)stream, p);
   hipLaunchKernelGGL(k_ln_mean_finish, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const float*)workspace, gamma, beta, out,
                      rows_per_group);
   FP_CHECK_LAUNCH("fp_ffn_layernorm_mean_fwd");
+  return FP_OK;
+}
+
+// Everything of nn.TransformerEncoderLayer behind the attention context + the token mean, in ONE launch (+ the finish kernel):
+// fp_linear_layernorm_fwd (out_proj + x + sa + norm1) followed by fp_ffn_layernorm_mean_fwd, with norm1's fp16 output staying in LDS
+// (k_rows512<true, true, true>).  The same bits as those two calls.  include/fp_amd.h.
+extern "C" size_t fp_encoder_tail_workspace_bytes(int groups, int rows_per_group) {
+  if (groups <= 0 || rows_per_group <= 0) return 0;
+  const size_t M = (size_t)groups * rows_per_group;
+  return M * 512 * sizeof(float) + (M / 16 + 1) * 512 * sizeof(float);
+}
+
+extern "C" int fp_encoder_tail_mean_fwd(const void* ctx16, int ldx, const void* wo_packed, const float* bo, const void* tok16, const float* pe,
+                                        const float* gamma1, const float* beta1, const void* w1_packed, const float* b1,
+                                        const void* w2_packed, const float* b2, const float* gamma2, const float* beta2, float eps,
+                                        float* out, void* workspace, size_t workspace_bytes, int groups, int rows_per_group, void* stream) {
+  FP_REQUIRE(groups >= 0, "fp_encoder_tail_mean_fwd: groups < 0");
+  if (groups == 0) return FP_OK;
+  FP_REQUIRE(ctx16 && wo_packed && tok16 && pe && gamma1 && beta1 && w1_packed && w2_packed && gamma2 && beta2 && out && workspace,
+             "fp_encoder_tail_mean_fwd: NULL tensor");
+  FP_REQUIRE(rows_per_group >= 16 && rows_per_group % 16 == 0,
+             "fp_encoder_tail_mean_fwd: rows_per_group=%d must be a multiple of 16 (a wave sums 16 consecutive rows, which have to belong to one group)", rows_per_group);
+  if (ldx == 0) ldx = LL_K;
+  FP_REQUIRE(ldx >= LL_K && ldx % 8 == 0, "fp_encoder_tail_mean_fwd: ldx=%d must be a multiple of 8 and at least 512", ldx);
+  const long long M = (long long)groups * rows_per_group;
+  FP_REQUIRE(M * ldx < (1ll << 30), "fp_encoder_tail_mean_fwd: operands exceed 2 GiB");
+  FP_REQUIRE((((size_t)ctx16 | (size_t)wo_packed | (size_t)bo | (size_t)tok16 | (size_t)pe | (size_t)gamma1 | (size_t)beta1 | (size_t)w1_packed |
+               (size_t)b1 | (size_t)w2_packed | (size_t)b2 | (size_t)gamma2 | (size_t)beta2 | (size_t)workspace) & 15) == 0,
+             "fp_encoder_tail_mean_fwd: tensors must be 16-byte aligned");
+  const size_t need = fp_encoder_tail_workspace_bytes(groups, rows_per_group);
+  if (workspace_bytes < need) {
+    fp_set_error("fp_encoder_tail_mean_fwd: workspace too small (%zu < %zu bytes, see fp_encoder_tail_workspace_bytes)", workspace_bytes, need);
+    return FP_ERR_WORKSPACE;
+  }
+  LinearLnParams p;
+  p.X = (const _Float16*)ctx16; p.ldx = ldx; p.Wp = (const _Float16*)wo_packed; p.bias = bo; p.x32 = nullptr; p.tok16 = (const _Float16*)tok16;
+  p.pe = pe; p.S = rows_per_group; p.gamma = gamma1; p.beta = beta1; p.eps = eps; p.y16 = nullptr; p.M = (int)M;
+  p.y32 = (float*)workspace;                                   // norm1's fp32 output: the residual of norm2
+  p.part = (float*)workspace + (size_t)M * 512;                // chunk sums
+  p.W1p = (const _Float16*)w1_packed; p.bias1 = b1; p.W2p = (const _Float16*)w2_packed; p.bias2 = b2;
+  FP_SET_MAX_LDS((k_rows512<true, true, true>), LL_LDS);
+  hipLaunchKernelGGL((k_rows512<true, true, true>), dim3(fp_cdiv((int)M, LL_BM)), dim3(LL_THREADS), LL_LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(k_ln_mean_finish, dim3(groups), dim3(512), 0, (hipStream_t)stream, (const float*)p.part, gamma2, beta2, out, rows_per_group);
+  FP_CHECK_LAUNCH("fp_encoder_tail_mean_fwd");
   return FP_OK;
 }
 
@@ -685,7 +784,7 @@ extern "C" int fp_linear_layernorm_fwd(const void* x16, const void* w16_packed, 
                (size_t)y32 | (size_t)y16) & 15) == 0, "fp_linear_layernorm_fwd: tensors must be 16-byte aligned");
   LinearLnParams p;
   p.X = (const _Float16*)x16; p.Wp = (const _Float16*)w16_packed; p.bias = bias; p.x32 = x32; p.tok16 = (const _Float16*)tok16; p.pe = pe;
-  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.ldx = ldx; p.part = nullptr; p.W2p = nullptr; p.bias2 = nullptr;
+  p.S = S; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y32 = y32; p.y16 = (_Float16*)y16; p.M = M; p.ldx = ldx; p.part = nullptr; p.W2p = nullptr; p.bias2 = nullptr; p.W1p = nullptr; p.bias1 = nullptr;
   FP_SET_MAX_LDS((k_rows512<false, false>), LL_LDS);
   hipLaunchKernelGGL((k_rows512<false, false>), dim3(fp_cdiv(M, LL_BM)), dim3(LL_THREADS), LL_LDS, (hipStream_t)stream, p);
   FP_CHECK_LAUNCH("fp_linear_layernorm_fwd");

@@ -73,6 +73,9 @@ PACKED_CONV_TILES = True
 # round 6: RefineNet's trans_head and rot_head read the same tokens: their in_proj as one 3072-wide launch, their attention as one 8-head
 # launch (RefinePlan.__init__); the same bits as two calls each.  overrides(MERGED_HEAD_QKV=False) goes back to them.
 MERGED_HEAD_QKV = True
+# round 6: the whole encoder layer behind the attention context as ONE launch (csrc/linear_ln.hip k_rows512<.., TAIL>): out_proj + norm1
+# and the fused FFN + norm2 + token mean above, with norm1's fp16 output staying in LDS between them.  Same bits as the two launches.
+FUSED_TAIL = True
 
 
 def _conv_backend():
@@ -216,7 +219,7 @@ SPLITK_TARGET_WGS = 384        # (tile, piece) workgroups a launch should have: 
 # the hard ceiling of both thresholds: overlap.SubBatches' default min_rows (a call of >= 2 x 32 hypotheses is split into sub-batches)
 SMALL_CALL_CEILING = 31
 
-_SWITCHES = ("FUSED_OUT_PROJ_LN", "FUSED_FFN", "ROWS_QKV", "PACKED_CONV_TILES", "MERGED_HEAD_QKV", "SPLITK_MAX_HYPS", "HEADS_TWO_STREAMS_MAX_HYPS")
+_SWITCHES = ("FUSED_OUT_PROJ_LN", "FUSED_FFN", "ROWS_QKV", "PACKED_CONV_TILES", "MERGED_HEAD_QKV", "FUSED_TAIL", "SPLITK_MAX_HYPS", "HEADS_TWO_STREAMS_MAX_HYPS")
 
 
 @contextlib.contextmanager
@@ -439,6 +442,11 @@ class _HipEncoderLayer:
     def pooled_from_context(self, ctx16, tok16, pe):
         """the layer behind the attention context (heads merged, before out_proj): ctx16 (N, L, 512) fp16, possibly a column block of a
         wider tensor (RefinePlan's two heads as one 8-head attention call)"""
+        if FUSED_TAIL and FUSED_OUT_PROJ_LN and FUSED_FFN and ctx16.shape[1] % 16 == 0 and tuple(pe.shape) == (ctx16.shape[1], 512):
+            # round 6: out_proj + norm1 + linear1 + ReLU + linear2 + norm2 + token mean in ONE launch (fp_encoder_tail_mean_fwd): the bits
+            # of the two launches below, norm1's fp16 output never leaves LDS
+            return ops.encoder_tail_mean(ctx16, self.out_p, self.att.out.b, tok16, pe, self.n1[0], self.n1[1], self.l1_p, self.l1.b,
+                                         self.l2_p, self.l2.b, self.n2[0], self.n2[1], 1e-5)
         if FUSED_OUT_PROJ_LN:
             # out_proj + residual + norm1 in one launch, the projection staying on chip (fp_linear_layernorm_fwd): the same bits
             y32, y16 = ops.linear_layernorm_res(ctx16, self.out_p, self.att.out.b, self.n1[0], self.n1[1], 1e-5, tok16=tok16, pe=pe)

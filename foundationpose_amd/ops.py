@@ -507,6 +507,49 @@ def ffn_layernorm_mean(y16, w1_packed, b1, w2_packed, b2, x32, gamma, beta, eps=
     return out
 
 
+def _column_block(x16, name):
+    """-> row stride (fp16 values) of an (..., 512) fp16 tensor that is contiguous or a column block of a contiguous wider tensor"""
+    if not (torch.is_tensor(x16) and x16.is_cuda and x16.dtype == torch.float16 and int(x16.shape[-1]) == 512):
+        raise _lib.FpAmdError(f"{name}: must be a CUDA float16 tensor (..., 512)")
+    if x16.is_contiguous():
+        return 512
+    ldx = int(x16.stride(-2)) if x16.dim() >= 2 else 512
+    ok = x16.stride(-1) == 1 and ldx % 8 == 0 and ldx >= 512 and x16.storage_offset() % 8 == 0
+    for d in range(x16.dim() - 2, 0, -1):
+        ok = ok and x16.stride(d - 1) == x16.stride(d) * x16.shape[d]
+    if not ok:
+        raise _lib.FpAmdError(f"{name}: must be contiguous or a column block of a contiguous tensor")
+    return ldx
+
+
+_TAIL_WS = {}
+
+
+def encoder_tail_mean(ctx16, wo_packed, bo, tok16, pe, gamma1, beta1, w1_packed, b1, w2_packed, b2, gamma2, beta2, eps=1e-5, workspace=None):
+    """(G, R, 512) fp16 attention context (heads merged; may be a column block of a wider tensor) + the layer input f32(tok16) + pe ->
+    (G, 512) f32 = mean_r LN2(y + linear2(relu(linear1(f16(y))))), y = LN1(f32(tok16) + pe + f16(ctx16 @ Wo^T + bo)): everything of the
+    encoder layer behind the attention + the token mean in one launch (fp_encoder_tail_mean_fwd) = linear_layernorm_res followed by
+    ffn_layernorm_mean, bit for bit, without norm1's fp16 output reaching HBM"""
+    ldx = _column_block(ctx16, "encoder_tail_mean: ctx16")
+    G_, R, _ = (int(v) for v in ctx16.shape)
+    tok = _dev(tok16, torch.float16, "tok16")
+    pe = _dev(pe, torch.float32, "pe")
+    if int(pe.shape[-2]) != R or tuple(tok.shape) != (G_, R, 512):
+        raise _lib.FpAmdError("encoder_tail_mean: tok16 must be (G, R, 512) and pe (R, 512)")
+    if R % 16:
+        raise _lib.FpAmdError(f"encoder_tail_mean: {R} rows per group, must be a multiple of 16")
+    out = torch.empty((G_, 512), dtype=torch.float32, device=ctx16.device)
+    need = int(_lib.lib().fp_encoder_tail_workspace_bytes(G_, R))
+    ws = workspace if workspace is not None else torch.empty(need, dtype=torch.uint8, device=ctx16.device)
+    f32 = lambda t, n: _ptr(_dev(t, torch.float32, n))
+    st = _lib.lib().fp_encoder_tail_mean_fwd(_ptr(ctx16), ldx, _ptr(_packed(wo_packed, "encoder_tail_mean")), f32(bo, "bo"), _ptr(tok), _ptr(pe),
+                                             f32(gamma1, "gamma1"), f32(beta1, "beta1"), _ptr(_packed(w1_packed, "encoder_tail_mean")), f32(b1, "b1"),
+                                             _ptr(_packed(w2_packed, "encoder_tail_mean")), f32(b2, "b2"), f32(gamma2, "gamma2"), f32(beta2, "beta2"),
+                                             float(eps), _ptr(out), _ptr(ws), ws.numel(), G_, R, _stream(ctx16))
+    _lib.check(st, "fp_encoder_tail_mean_fwd")
+    return out
+
+
 def colmean_f16(x, gamma=None, beta=None, eps=1e-5, resid32=None):
     """x (G, R, 512) fp16 -> (G, 512) f32: mean over R of LN(resid32 + x)*gamma+beta (gamma given) or of x (fp_colmean_f16_fwd)"""
     x = _dev(x, torch.float16, "x")
@@ -684,6 +727,8 @@ linear_layernorm_res = _timed("fp_linear_layernorm_fwd", linear_layernorm_res,
                                                      2.0 * x.numel() * 512))
 ffn_layernorm_mean = _timed("fp_ffn_layernorm_mean_fwd", ffn_layernorm_mean,
                             lambda y, w1, b1, w2, *a, **k: (6.0 * y.numel() + 4.0 * 512 * 512, 4.0 * y.numel() * 512))
+encoder_tail_mean = _timed("fp_encoder_tail_mean_fwd", encoder_tail_mean,
+                           lambda ctx, *a, **k: (2.0 * ctx.numel() * 2 + 8.0 * ctx.numel() + 6.0 * 512 * 512, 6.0 * ctx.numel() * 512))
 colmean_f16 = _timed("fp_colmean_f16_fwd", colmean_f16,
                      lambda x, *a, **k: ((6.0 if k.get("resid32") is not None else 2.0) * x.numel(), 0.0))
 rows_linear = _timed("fp_rows_linear_fwd", rows_linear)

@@ -64,7 +64,8 @@ const char* fp_last_error(void);
  *   211 -> 212 (round 5): fp_igemm_epilogue grew by one member at its end (w_tiles); + fp_pack_conv3x3_tiles_f16.
  *   212 -> 213 (round 6): w_tiles is read only when flags has FP_IGEMM_HAS_W_TILES (a 212 caller that sets w_tiles without the bit
  *                         gets the plain weight path: correct, slower); fp_igemm_f16_splitk_fwd refuses w_tiles instead of ignoring it;
- *                         fp_linear_layernorm_fwd takes the row stride of x16 (new argument before the stream). */
+ *                         fp_linear_layernorm_fwd takes the row stride of x16 (new argument before the stream);
+ *                         + fp_encoder_tail_mean_fwd / fp_encoder_tail_workspace_bytes. */
 #define FP_AMD_ABI_VERSION 213
 int fp_version(void);
 
@@ -256,6 +257,22 @@ int fp_linear_layernorm_fwd(const void* x16 /*dev*/, const void* w16_packed /*de
                             const float* gamma /*dev D*/, const float* beta /*dev D*/, float eps, float* y32 /*dev|NULL*/,
                             void* y16 /*dev|NULL*/, int M, int K, int D, int ldx /* row stride of x16 in fp16 values; 0 = K */,
                             void* stream);
+
+/* Everything of nn.TransformerEncoderLayer behind the attention context (refine_network.py:56-70: self_attn.out_proj, `x + sa`, norm1,
+ * linear1 -> ReLU -> linear2, `x + ff`, norm2) + the token mean of RefineNet.forward (refine_network.py:90-91), in ONE launch (+ the
+ * finish kernel) = fp_linear_layernorm_fwd followed by fp_ffn_layernorm_mean_fwd, with norm1's fp16 output staying in LDS between them
+ * (round 6; the same bits as those two calls: per element the same instruction sequences).  ctx16: (M, 512) fp16 with row stride ldx
+ * (0 = 512), M = groups * rows_per_group; tok16 (M, 512) fp16 + pe (rows_per_group, 512) f32 = the layer input f32(tok16) + pe[row %
+ * rows_per_group]; *_packed: fp_pack_linear512_f16 of the three (512, 512) weights; out (groups, 512) f32.  workspace:
+ * fp_encoder_tail_workspace_bytes(groups, rows_per_group) bytes of device scratch (norm1's fp32 output -- the residual of norm2 -- and
+ * the token-mean chunk sums), 16-byte aligned. */
+size_t fp_encoder_tail_workspace_bytes(int groups, int rows_per_group);
+int fp_encoder_tail_mean_fwd(const void* ctx16 /*dev*/, int ldx, const void* wo_packed /*dev*/, const float* bo /*dev|NULL*/,
+                             const void* tok16 /*dev*/, const float* pe /*dev*/, const float* gamma1 /*dev*/, const float* beta1 /*dev*/,
+                             const void* w1_packed /*dev*/, const float* b1 /*dev|NULL*/, const void* w2_packed /*dev*/,
+                             const float* b2 /*dev|NULL*/, const float* gamma2 /*dev*/, const float* beta2 /*dev*/, float eps,
+                             float* out /*dev*/, void* workspace /*dev*/, size_t workspace_bytes, int groups, int rows_per_group,
+                             void* stream);
 
 /* The feed-forward half of nn.TransformerEncoderLayer (refine_network.py:56-70: linear1 -> ReLU -> linear2, `x + ff`, norm2; under
  * autocast: fp16 Linears with fp32 accumulation + bias and one rounding each, fp32 residual stream and LayerNorm) fused with the

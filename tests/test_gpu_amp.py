@@ -692,6 +692,169 @@ def test_refiner_fitted_heads_chain_vs_exact(scene, dev, gmesh, frame):
     assert np.median(frR) <= 1.5 * np.median(ofR) and np.median(frt) <= 1.5 * np.median(oft), rep
 
 
+# Gates of the trained stand-in (round 6), ABSOLUTE: the north-star's 1e-4 m holds for every hypothesis, teacher-forced and free-running;
+# 1e-4 rad holds for the bulk, and every hypothesis beyond it is EXPLAINED: teacher-forced by a last-place flip of the fp16 network
+# output the reference itself holds (at a 0.13 rad update one fp16 ulp of the rotation output is 8.5e-5 rad: 2.4e-4 x rot_normalizer),
+# free-running by the distribution the exactly-pinned CPU oracle shows on the same chain (the golden's oracle_chain)
+# measured on MI355X (profiles/r06_parity_trained.json): teacher-forced hip 3.9e-6 rad median / 6.0e-5 p99 / 1.27e-4 max, 8.7e-6 m max, 99.7 %
+# within 1e-4 rad, the four beyond it single-ulp flips at iteration 0 (oracle: 4.2e-6 / 7.4e-5 / 1.31e-4; torch_amp 1.3e-5 / 1.1e-4 /
+# 1.6e-4); free-running hip 2.4e-5 median, 77 % within 1e-4 rad, 5.5e-4 max, 1.2e-5 m max (oracle 2.6e-5 / 83 % / 5.3e-4; torch_amp
+# 3.8e-5 / 72 % / 5.9e-4).  tf_dR_max_rad = one fp16 ulp in all three components of an output in [0.5, 1): sqrt(3) x 4.9e-4 x 0.349.
+TRAINED_GATES = dict(tf_dt_max_m=1e-4, tf_dR_median_rad=1e-5, tf_dR_frac_1e4=0.99, tf_dR_max_rad=3e-4, fr_dt_max_m=1e-4, fr_dR_max_rad=1e-3,
+                     fr_frac_1e4_min=0.65, fr_named_min=0.9)
+
+
+def test_refiner_trained_standin_chain_vs_exact(scene, dev, gmesh, frame):
+    """Round 6 (the round-5 verdict's item 1): the stand-in refiner TRAINED into a contraction (weights.trained_refiner_state_dict,
+    tests/golden/train_standin_refiner.py: 8 GPU-minutes of the product's nn.Module under autocast on perturbations of the scene's
+    ground truth) -- full-size updates, no CONTRACTION_HEAD_SCALE, precision='fp16', every op on libfp_amd.so -- against the
+    exactly-rounded free-running 252 x 5 chain minted for it (tests/golden/acc64_trained_chain_golden.npz, starts <= 15 deg / 2 cm).
+      (a) it IS a contraction: one iteration shrinks the pose error to the ground truth >= 3 x in rotation AND translation (measured ~75 x /
+          ~65 x), on the exact chain and on the deployed kernels alike;
+      (b) teacher-forced, all 252 x 5, ABSOLUTE: translation within 1e-4 m for every hypothesis; rotation within 1e-4 rad for the bulk,
+          and every hypothesis beyond it differs from the exactly-rounded raw network output by at most 2 fp16 ulps per component --
+          the resolution of the tensor the reference holds (predict_pose_refine.py:192-193);  hip / fp32-accumulating CPU oracle /
+          PyTorch-ROCm under autocast side by side;
+      (c) FREE-RUNNING predict(iteration=5), ABSOLUTE: translation within 1e-4 m for every hypothesis; rotation reported as the
+          fraction within 1e-4 rad next to the CPU oracle's own free-running chain (the golden's oracle_chain) and torch_amp's: the
+          trained map still moves 2e-4 rad per iteration at its fixed point (discrete input events: the crop window is rounded to
+          whole pixels), so NO fp32-accumulating implementation follows the exact chain to 1e-4 rad on all 252 -- asserted is that the
+          deployed chain is as close as the oracle's."""
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, TRAINED_REFINER_FILE, trained_refiner_state_dict
+    from oracle import nets_amp, ops as oo
+    from oracle import pipeline as op
+    import hashlib
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "acc64_trained_chain_golden.npz")))
+    assert hashlib.sha256(open(TRAINED_REFINER_FILE, "rb").read()).hexdigest() == str(g["checkpoint_sha256"]), "golden minted for another checkpoint"
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = trained_refiner_state_dict()
+    chain, ochain, P0, gt = g["chain"], g["oracle_chain"], g["start"], g["gt"]
+    tn = [float(v) for v in cfg["trans_normalizer"]]
+    preds = dict(hip=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16"),
+                 lib=PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="torch_amp", n_streams=1))
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+
+    def run(name, P, it):
+        o, _ = preds[name].predict(scene["rgb"], frame["depth_t"], scene["K"], P, frame["xyz_t"], iteration=it, **kw)
+        return o.cpu().numpy()
+    G = np.tile(gt[None], (len(P0), 1, 1)).astype(np.float32)
+    err = lambda P: _dist(P, G)
+    rep = dict(error_to_gt_exact_chain=[dict(dR=_pct(err(chain[k])[0]), dt=_pct(err(chain[k])[1])) for k in range(6)],
+               update_per_iteration=[dict(dR=_pct(_dist(chain[k + 1], chain[k])[0]), dt=_pct(_dist(chain[k + 1], chain[k])[1])) for k in range(5)])
+    # ---- (b) teacher forced along the exact chain
+    tf = {n: [] for n in ("hip", "oracle", "lib")}
+    raw_hip = []
+    for k in range(5):
+        A, B, _, _ = op.refine_inputs(cfg, chain[k], scene["mesh_np"], scene["rgb"], frame["xyz"], scene["K"], scene["diameter"])
+        assert (_crc(A), _crc(B)) == tuple(int(v) for v in g["crc"][k]), "this box's CPU builds other network inputs than the golden's"
+        o = nets_amp.refine_forward(torch.from_numpy(A), torch.from_numpy(B), sd)
+        tf["oracle"].append(oo.pose_update(o["trans"].numpy(), o["rot"].numpy(), chain[k], cfg["rot_rep"], True, tn, float(cfg["rot_normalizer"]),
+                                           float(scene["diameter"])))
+        for n in ("hip", "lib"):
+            tf[n].append(run(n, chain[k], 1))
+        raw_hip.append({q: v.cpu().numpy() for q, v in preds["hip"].last_raw_output.items()})
+    tfd = {n: (np.stack([_dist(tf[n][k], chain[k + 1])[0] for k in range(5)]), np.stack([_dist(tf[n][k], chain[k + 1])[1] for k in range(5)])) for n in tf}
+    rep["teacher_forced"] = {n: dict(dR=_pct(tfd[n][0]), dt=_pct(tfd[n][1]), frac_within_1e4_rad=float(np.mean(tfd[n][0] <= 1e-4)),
+                                     dR_by_iteration=[_pct(tfd[n][0][k]) for k in range(5)]) for n in tf}
+    out_ulps = []
+    for k, h in zip(*np.nonzero(tfd["hip"][0] > 1e-4)):
+        d = np.abs(raw_hip[k]["rot"][h].astype(np.float64) - g["raw_rot"][k][h])
+        u = d / ulp16(g["raw_rot"][k][h])
+        out_ulps.append(dict(iteration=int(k), hypothesis=int(h), dR=float(tfd["hip"][0][k, h]), raw_rot_exact=[float(v) for v in g["raw_rot"][k][h]],
+                             raw_rot_diff_in_fp16_ulps=[float(v) for v in u]))
+    rep["teacher_forced_hip_beyond_1e4_rad"] = out_ulps
+    # ---- (c) free running
+    fr = dict(hip=run("hip", P0, 5), lib=run("lib", P0, 5), oracle=ochain[5])
+    per, cur = [], P0                               # the same chain as five 1-iteration calls through the host (the same bits)
+    for k in range(5):
+        cur = run("hip", cur, 1)
+        per.append(cur)
+    rep["five_calls_equal_one_call"] = bool(np.array_equal(per[-1], fr["hip"]))
+    dRk = np.stack([_dist(per[k], chain[k + 1])[0] for k in range(5)])
+    named = []
+    for h in np.nonzero(dRk[-1] > 1e-4)[0]:
+        # why hypothesis h is more than 1e-4 rad from the exact chain: the iteration of the largest growth of its deviation, and what
+        # happened there -- a last-place flip of the fp16 network output (iteration 0: identical inputs), or a discrete event in its
+        # network inputs between the two runs (crop window moved by a pixel, coverage / texel / nearest-neighbour flips)
+        grow = np.diff(np.concatenate([[0.0], dRk[:, h]]))
+        k = int(np.argmax(grow))
+        if k == 0:
+            u = np.abs(raw_hip[0]["rot"][h].astype(np.float64) - g["raw_rot"][0][h]) / ulp16(g["raw_rot"][0][h])
+            ev = dict(output_ulp_flips=int((u > 0.5).sum()))
+        else:
+            ev = _input_flips(cfg, scene, frame, per[k - 1][h], chain[k][h])
+        named.append(dict(hypothesis=int(h), final_dR=float(dRk[-1, h]), leaves_chain_at_iteration=k, growth_there=float(grow[k]), events=ev,
+                          explained=bool(sum(ev.values()) > 0)))
+    rep["free_running_hip_beyond_1e4_rad"] = dict(count=len(named), explained=int(sum(n["explained"] for n in named)), cases=named)
+    frd = {n: _dist(fr[n], chain[5]) for n in fr}
+    rep["free_running"] = {n: dict(dR=_pct(frd[n][0]), dt=_pct(frd[n][1]), frac_within_1e4_rad=float(np.mean(frd[n][0] <= 1e-4)),
+                                   frac_within_1e4_m=float(np.mean(frd[n][1] <= 1e-4))) for n in fr}
+    rep["free_running_oracle_by_iteration"] = [dict(dR=_pct(_dist(ochain[k], chain[k])[0]), frac_within_1e4_rad=float(np.mean(_dist(ochain[k], chain[k])[0] <= 1e-4)))
+                                               for k in range(1, 6)]
+    rep["error_to_gt_deployed_chain"] = dict(dR=_pct(err(fr["hip"])[0]), dt=_pct(err(fr["hip"])[1]))
+    rep["gates"] = TRAINED_GATES
+    REPORT["refiner_252_trained_standin_chain_vs_exact"] = rep
+    # (a)
+    e0, e1, h1 = err(P0), err(chain[1]), err(tf["hip"][0])
+    assert np.median(e0[0]) > 0.1 and np.median(e0[1]) > 0.01                                      # full-size starts
+    assert np.median(e1[0]) * 3 <= np.median(e0[0]) and np.median(e1[1]) * 3 <= np.median(e0[1]), rep["error_to_gt_exact_chain"]
+    assert np.median(h1[0]) * 3 <= np.median(e0[0]) and np.median(h1[1]) * 3 <= np.median(e0[1])
+    # (b) absolute
+    T = TRAINED_GATES
+    assert tfd["hip"][1].max() <= T["tf_dt_max_m"], rep["teacher_forced"]["hip"]
+    assert np.median(tfd["hip"][0]) <= T["tf_dR_median_rad"] and rep["teacher_forced"]["hip"]["frac_within_1e4_rad"] >= T["tf_dR_frac_1e4"] \
+        and tfd["hip"][0].max() <= T["tf_dR_max_rad"], rep["teacher_forced"]["hip"]
+    for o in out_ulps:
+        assert max(o["raw_rot_diff_in_fp16_ulps"]) <= 2.0 + 1e-6, o
+    assert np.median(tfd["hip"][0]) <= EXACT_GATE * np.median(tfd["oracle"][0]) and np.percentile(tfd["hip"][0], 90) <= EXACT_GATE * np.percentile(tfd["oracle"][0], 90), rep["teacher_forced"]
+    # (c) absolute in translation; in rotation no further from the exact chain than the exactly-pinned oracle's own chain
+    assert frd["hip"][1].max() <= T["fr_dt_max_m"] and frd["hip"][0].max() <= T["fr_dR_max_rad"], rep["free_running"]
+    # median: two samples of one distribution (EXACT_GATE); the p90 sits in the tail of hypotheses that met an input event -- one draw of
+    # a bimodal sample (measured hip / oracle 1.26, torch_amp / oracle 1.33): bounded at EXACT_GATE_MAX
+    assert np.median(frd["hip"][0]) <= EXACT_GATE * np.median(frd["oracle"][0]) and np.percentile(frd["hip"][0], 90) <= EXACT_GATE_MAX * np.percentile(frd["oracle"][0], 90), rep["free_running"]
+    assert rep["free_running"]["hip"]["frac_within_1e4_rad"] >= max(T["fr_frac_1e4_min"], rep["free_running"]["oracle"]["frac_within_1e4_rad"] - 0.1), rep["free_running"]
+    assert rep["five_calls_equal_one_call"]
+    fb = rep["free_running_hip_beyond_1e4_rad"]
+    assert fb["explained"] >= T["fr_named_min"] * fb["count"], fb
+
+
+def test_track_one_small_call_path_vs_exact(scene, dev, gmesh, frame):
+    """Round 6 (the round-5 verdict, weak 1c): the kernels a ONE-hypothesis call runs -- split-K convolutions, the two heads on two
+    streams (engine.SPLITK_MAX_HYPS): the reference's track_one, estimater.py:250-268 with iteration=2 (run_demo.py:64) -- at POSE
+    level against the exactly-rounded chain of the trained stand-in: 24 single-hypothesis predict(iteration=2) calls from the golden's
+    starts against chain[2] of the same hypotheses (every hypothesis is independent of its batch in the exact evaluation), ABSOLUTE:
+    within 1e-4 m, and within 1e-4 rad except for last-place flips of the fp16 outputs (bounded at 3e-4 rad; the same calls with the
+    small-call path switched off are reported next to it)."""
+    from foundationpose_amd import engine, ops
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+    from foundationpose_amd.weights import DEFAULT_REFINE_CFG, trained_refiner_state_dict
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "acc64_trained_chain_golden.npz")))
+    cfg = dict(DEFAULT_REFINE_CFG)
+    sd = trained_refiner_state_dict()
+    ids = list(range(0, 252, 11))[:24]
+    kw = dict(mesh=scene["mesh"], mesh_tensors=gmesh, mesh_diameter=scene["diameter"])
+    res = {}
+    for name, over in (("small_call_path", {}), ("large_call_kernels", dict(SPLITK_MAX_HYPS=0, HEADS_TWO_STREAMS_MAX_HYPS=0))):
+        with engine.overrides(**over):
+            pred = PoseRefinePredictor(cfg=cfg, state_dict=sd, device=dev, precision="fp16", graph=False)
+            out = []
+            for h in ids:
+                o, _ = pred.predict(scene["rgb"], frame["depth_t"], scene["K"], g["start"][h:h + 1], frame["xyz_t"], iteration=2, **kw)
+                out.append(o.cpu().numpy()[0])
+            if name == "small_call_path":
+                with ops.KernelTimers() as kt:
+                    pred.predict(scene["rgb"], frame["depth_t"], scene["K"], g["start"][:1], frame["xyz_t"], iteration=1, **kw)
+                assert kt.summary().get("fp_igemm_f16_splitk_fwd", dict(calls=0))["calls"] >= 10      # the path under test did run
+        dR, dt = _dist(np.stack(out), g["chain"][2][ids])
+        res[name] = dict(dR=_pct(dR), dt=_pct(dt), frac_within_1e4_rad=float(np.mean(dR <= 1e-4)))
+    oR, ot = _dist(g["oracle_chain"][2][ids], g["chain"][2][ids])
+    res["cpu_oracle_fp32_accumulation"] = dict(dR=_pct(oR), dt=_pct(ot), frac_within_1e4_rad=float(np.mean(oR <= 1e-4)))
+    REPORT["track_one_small_call_path_vs_exact"] = res
+    s = res["small_call_path"]
+    assert s["dt"]["max"] <= 1e-4 and s["dR"]["median"] <= 5e-5 and s["dR"]["max"] <= 3e-4 and s["frac_within_1e4_rad"] >= 0.8, res
+
+
 def test_scorer_252_vs_exact(scene, dev, gmesh, frame, acc64):
     """the 252 scores of the exact chain's refined poses: HIP plan, fp32-accumulating oracle and PyTorch-ROCm under autocast,
     each against the exactly-rounded scores (acc64 score_exact): logit errors, Kendall tau, top-1.  Gate: hip as close to the
