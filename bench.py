@@ -40,7 +40,7 @@ SCORE_GFLOP_CROSS_252 = 0.659
 STEM_GFLOP_PER_IMAGE = (80 * 80 * 64 * 6 * 49 + 40 * 40 * 128 * 64 * 9 + 4 * 40 * 40 * 128 * 128 * 9) * 2 / 1e9   # encodeA, one 160x160 image
 # roofline that bounds each hand-written kernel (DESIGN.md "Kernels")
 KERNEL_BOUND = {"fp_render_crops": "hbm", "fp_warp_crops": "hbm", "fp_conv7x7s2_bn_relu_fwd": "hbm",
-                "fp_igemm_f16_fwd": "mfma", "fp_linear512_f16_fwd": "mfma", "fp_linear_layernorm_fwd": "mfma", "fp_ffn_layernorm_mean_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
+                "fp_igemm_f16_fwd": "mfma", "fp_linear512_f16_fwd": "mfma", "fp_linear_layernorm_fwd": "mfma", "fp_ffn_layernorm_mean_fwd": "mfma", "fp_encoder_tail_mean_fwd": "mfma", "fp_layernorm_res_fwd": "hbm", "fp_add_pe_f16_fwd": "hbm",
                 "fp_colmean_f16_fwd": "hbm", "fp_attention_f16_fwd": "mfma"}
 
 
@@ -231,14 +231,14 @@ def tracking_bench(dev, sc, refiner, seq, hyps, iters, latency_frames=200):
         from foundationpose_amd.graphs import FramePipeline
         pipe = FramePipeline(trk)
 
-        def run_pipelined(n, sync_each=False, keep=0):
+        def run_pipelined(n, sync_each=False, keep=0, graph=True):
             outs, ls = [], []
             pipe.submit(0, rgb_h[0], depth_h[0], hyp_h[0])
             for f in range(n):
                 t1 = time.perf_counter()
                 if f + 1 < n:
                     pipe.submit((f + 1) % 2, rgb_h[f + 1], depth_h[f + 1], hyp_h[f + 1])
-                o = pipe.run(f % 2)
+                o = pipe.run(f % 2, graph=graph)
                 if f < keep:
                     outs.append(o.clone())
                 if sync_each:
@@ -250,6 +250,10 @@ def tracking_bench(dev, sc, refiner, seq, hyps, iters, latency_frames=200):
         t0 = time.perf_counter()
         run_pipelined(F_)
         res["pipelined"] = (time.perf_counter() - t0) / F_
+        run_pipelined(5, graph=False)
+        t0 = time.perf_counter()
+        run_pipelined(F_, graph=False)
+        res["pipelined_eager"] = (time.perf_counter() - t0) / F_
         _, ls = run_pipelined(min(F_, latency_frames), sync_each=True)
         lat["pipelined"] = {"median": float(np.median(ls) * 1e3), "p95": float(np.percentile(ls, 95) * 1e3)}
         keep = min(F_, 12)
@@ -257,6 +261,7 @@ def tracking_bench(dev, sc, refiner, seq, hyps, iters, latency_frames=200):
         same = all(bool(torch.equal(po[f], frame(f, True))) for f in range(keep))
     return {"frames": F_, "hypotheses_per_frame": hyps, "refine_iterations": iters, "distinct_frames": F_,
             "pipelined_ms_per_frame": res["pipelined"] * 1e3, "frames_per_sec_pipelined": 1.0 / res["pipelined"],
+            "pipelined_eager_ms_per_frame": res["pipelined_eager"] * 1e3,
             "latency_ms_synced_per_frame_pipelined": lat["pipelined"], "pipelined_poses_equal_unpipelined": bool(same),
             "ingest_stream_overlaps": pipe.ingest_overlaps,
             "uploads_per_frame_bytes": int(rgb_h[0].numel() + depth_h[0].numel() * 4 + hyp_h[0].numel() * 4),

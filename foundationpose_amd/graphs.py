@@ -156,9 +156,9 @@ class GraphedTracker:
         self.refiner.refine_part(h, self.parts[h], self.rgb, xyz, self.poses_in, self.K, self.H, self.W, self.handle,
                                  self.diameter, range(self.R), self.outs, self.workspace[h])
 
-    def _body(self):
-        """the frame without graphs: same launches, same streams"""
-        xyz = self._pre()
+    def _body(self, xyz=None):
+        """the frame without graphs: same launches, same streams (xyz given: the refine loop alone, on that map)"""
+        xyz = self._pre() if xyz is None else xyz
         streams = self.refiner.sub.streams(self.dev, len(self.parts))
         self.refiner.sub.fork(streams)
         for h in range(len(self.parts)):
@@ -304,8 +304,9 @@ class FramePipeline:
         return st, False
 
     @torch.inference_mode()
-    def run(self, slot):
-        """refine the frame staged in `slot` on the current stream -> the tracker's static output buffer (valid until the next run)"""
+    def run(self, slot, graph=True):
+        """refine the frame staged in `slot` on the current stream -> the tracker's static output buffer (valid until the next run).
+        graph=False: the same launches issued eagerly (A/B; the same bits)"""
         t = self.trk
         cur = torch.cuda.current_stream(t.dev)
         cur.wait_event(self.ready[slot])
@@ -319,4 +320,4 @@ class FramePipeline:
             raise RuntimeError("FramePipeline.run: no previous output to track from, submit poses with the first frame")
         self.free[slot].record(cur)
         t._have_output = True
-        return t.replay_parts()
+        return t.replay_parts() if graph else t._body(t.xyz)

@@ -19,8 +19,8 @@ import sys
 
 ENTRY = [("k_vertex", "fp_render_crops"), ("k_bin", "fp_render_crops"), ("k_raster", "fp_render_crops"), ("k_warp", "fp_warp_crops"),
          ("k_conv7x7s2", "fp_conv7x7s2_bn_relu_fwd"), ("k_stem", "fp_stem_fwd"), ("k_conv_sw", "fp_igemm_f16_fwd"), ("k_igemm_pp", "fp_igemm_f16_fwd"),
-         ("k_igemm_f16", "fp_igemm_f16_fwd"), ("k_rows512<true, true>", "fp_ffn_layernorm_mean_fwd"), ("k_rows512", "fp_linear_layernorm_fwd"), ("k_pack_w512", "fp_pack_linear512_f16"), ("k_linear512", "fp_linear512_f16_fwd"),
-         ("k_ln_mean_finish", "fp_ffn_layernorm_mean_fwd"), ("k_layernorm_res512", "fp_layernorm_res_fwd"), ("k_colmean512", "fp_colmean_f16_fwd"),
+         ("k_igemm_f16", "fp_igemm_f16_fwd"), ("k_rows512<true, true, true>", "fp_encoder_tail_mean_fwd"), ("k_rows512<true, true", "fp_ffn_layernorm_mean_fwd"), ("k_rows512", "fp_linear_layernorm_fwd"), ("k_pack_w512", "fp_pack_linear512_f16"), ("k_linear512", "fp_linear512_f16_fwd"),
+         ("k_ln_mean_finish", "fp_encoder_tail_mean_fwd"), ("k_layernorm_res512", "fp_layernorm_res_fwd"), ("k_colmean512", "fp_colmean_f16_fwd"),
          ("k_attention_f16", "fp_attention_f16_fwd"), ("k_rows_linear", "fp_rows_linear_fwd")]
 
 
