@@ -13,7 +13,6 @@ capture.  Every buffer a sub-batch touches is its own: the encoder's activation 
 scratch by stream (ops._workspace) or passed per part by the caller.
 """
 import logging
-import os
 
 import numpy as np
 import torch
@@ -25,6 +24,11 @@ log = logging.getLogger(__name__)
 # of hardware queues, and streams that share a queue serialise -- with one side stream each for the refiner and the scorer
 # plus RCCL's stream, the RCCL bench ran SLOWER than one stream (46 ms against 41 ms per step)
 _SIDE = {}
+# Experiment / test switches (round 6: module constants, not environment variables -- the release package reads none).  FORCE_OVERLAP:
+# None = probe the side stream and run the exactness canary (the product), True / False = skip both and force sub-batch overlap on /
+# off for side streams created from now on; SIDE_PRIORITY: HIP priority of the side streams (0 = default).
+FORCE_OVERLAP = None
+SIDE_PRIORITY = 0
 
 
 def reserve_streams(device, k=1):
@@ -37,14 +41,12 @@ def reserve_streams(device, k=1):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     side = _SIDE.setdefault(idx, [])
     while len(side) < k:
-        prio = os.environ.get("FP_AMD_SIDE_PRIORITY", "").strip()      # experiment knob: HIP priority of the side stream
-        st = torch.cuda.Stream(device=device, priority=int(prio)) if prio not in ("", "0") else torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=int(SIDE_PRIORITY)) if SIDE_PRIORITY else torch.cuda.Stream(device=device)
         with torch.cuda.stream(st):                  # first use: the runtime binds a stream to its hardware queue lazily
             torch.zeros(1, device=device)
         side.append(st)
-        force = os.environ.get("FP_AMD_OVERLAP", "").strip()      # "0" / "1": skip the probes and force the decision
-        if force in ("0", "1"):
-            ok, why = force == "1", "forced by FP_AMD_OVERLAP"
+        if FORCE_OVERLAP is not None:                              # True / False: skip the probes and force the decision
+            ok, why = bool(FORCE_OVERLAP), "forced by overlap.FORCE_OVERLAP"
         else:
             ok = _overlaps_with_current(st, device)
             why = "side stream runs beside the main stream" if ok else "side stream shares the main stream's hardware queue"

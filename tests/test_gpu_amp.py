@@ -348,7 +348,7 @@ def test_hip_encoder_matches_amp_oracle(dev, use_bn):
     # the fused positional table: the in_proj operand is the fp16 rounding of fp16 tokens + fp32 table
     assert torch.equal(x16.cpu(), (hip.float().cpu() + sd["pos_embed.pe"].float()[:, :400]).half())
     # first block: a 294-term reduction, compared on its own buffer (interior of the padded NHWC activation)
-    c1 = enc._bufs[(n, 160, 160, 0)]["P1"][:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu()
+    c1 = enc._buffers(n, 160, 160, 0)["P1"][:, 1:-1, 1:-1].permute(0, 3, 1, 2).float().cpu()
     r1 = flip_report(c1.numpy(), tr["conv1"].numpy())
     rep = flip_report(hip.float().cpu().numpy(), tr["tok16"].numpy())
     REPORT.setdefault("encoder_vs_oracle", {})[f"bn{int(use_bn)}"] = dict(conv1=r1, tokens=rep)

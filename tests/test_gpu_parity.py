@@ -876,7 +876,7 @@ def test_shared_observed_crop_changes_nothing(scene, dev, gmesh, frame):
         plan = refiner.plan()
         enc_call = plan.enc.__call__
         plan.enc.__class__ = type("_CountingEncoder", (plan.enc.__class__,), {
-            "__call__": lambda self, AB, slot=0, shared_b=False: (calls.append((int(AB.shape[0]), bool(shared_b))), enc_call(AB, slot, shared_b))[1]})
+            "__call__": lambda self, AB, slot=0, shared_b=False, small_calls=True: (calls.append((int(AB.shape[0]), bool(shared_b))), enc_call(AB, slot, shared_b, small_calls))[1]})
         for n, it in ((75, 1), (75, 3), (2, 2)):
             P = scene["poses"][:n]
             calls.clear()
