@@ -502,6 +502,10 @@ static int sw_variant(const IgemmParams& p) {
   }
   if (forced >= 0) v = forced;
 #endif
+  // 2 / 3 (round 6 A/B builds): the two-per-CU lock-step kernel only where it measured ahead of the ping-pong kernel at sub-batch size
+  // (DESIGN_HISTORY 3.2: 128 -> 128 +3-5 %, 256 -> 256 +2-3 %, 512 -> 512 -12 %): layers of up to 128 / 256 input channels
+  if (v == 2) v = p.Cin <= 128 ? 1 : 0;
+  if (v == 3) v = p.Cin <= 256 ? 1 : 0;
   if (v == 1 && sw_span(p.in, 256) > LS_PROWS) v = 0;
   return v;
 }
