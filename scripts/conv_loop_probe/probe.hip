@@ -1,0 +1,319 @@
+// Main-loop probe for the shifted-window convolution (round 6; DESIGN_HISTORY 8.1 "a different division of labour"): how many shader
+// clocks does ONE k-step (32 channels x 1 tap of a 512 x 128 tile: 128 v_mfma_f32_32x32x16_f16 per CU = 1024 clk per SIMD) take under
+// different divisions of the same operand traffic among the waves of a CU?  No convolution is computed: the LDS / LDS-DMA / MFMA
+// instruction mix, the buffer sizes, the barrier structure and the operand sources (weights from a 1.2 MB L2-resident array, patches
+// streamed from a 512 MB array) are those of k_conv_sw<512,128,4>; addresses are synthetic.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/cvprobe scripts/conv_loop_probe/probe.hip && /tmp/cvprobe
+//   PP8   : the product's schedule -- 8 waves, two groups of 4 one cluster apart; a wave: 12 ds_read_b128 + its LDS-DMA pieces | barrier |
+//           16 MFMAs | barrier
+//   LS4   : 4 waves (one per SIMD, the whole register file), a wave owns 128 px x 128 ch = 32 MFMAs per k-step; the 16 fragment reads
+//           of k-step s + 1 and the step's 3 LDS-DMA pieces are interleaved with the MFMAs of k-step s; ONE barrier per k-step
+//   *_M   : the same loops with the MFMAs only (what the matrix pipe does alone under each wave shape)
+//   *_ND  : no LDS-DMA in the loop;  *_NR: no fragment reads in the loop;  PP8_LW / _DF / _MEM: see main()
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16_ __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int ROWB = 64, PATCH_ROWS = 640, PATCH_BYTES = PATCH_ROWS * ROWB, W_BYTES = 128 * ROWB, NSTW = 4;
+constexpr int LDS_BYTES = 2 * PATCH_BYTES + NSTW * W_BYTES;     // 80 KiB + 32 KiB
+
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, unsigned char* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+
+// FLAGS: 1 = no MFMA-free parts (i.e. MFMA only), 2 = no DMA, 4 = no fragment reads
+template <int FLAGS>
+__global__ __launch_bounds__(512, 1) void k_pp8(const _Float16* __restrict__ W, const _Float16* __restrict__ P, float* out, unsigned long long* clk, int ksteps, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool MONLY = FLAGS & 1, NODMA = FLAGS & 2, NOREAD = FLAGS & 4, LATEWAIT = FLAGS & 8, NOMFMA = FLAGS & 16, DMAFIRST = FLAGS & 32, WLATE = FLAGS & 64, DMACOMP = FLAGS & 128, RCOMP = FLAGS & 256, RC2 = FLAGS & 512;
+  unsigned char* patch = smem; unsigned char* wring = smem + 2 * PATCH_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wid >> 2;
+  const int wm = wid >> 1, wn = wid & 1, frow = lane & 31, fhalf = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(W), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(P), 0, 0x7FFFFFFF, 0x00020000);
+  float16_ acc[2][4];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  half8 fa[2][4], fw[2][2], fw2[2][2], fa2[2][4];
+  for (int a = 0; a < 2; ++a) for (int j = 0; j < 4; ++j) for (int e = 0; e < 8; ++e) fa2[a][j][e] = (_Float16)(0.004f * (lane + e + j));
+  for (int a = 0; a < 2; ++a) for (int j = 0; j < 2; ++j) for (int e = 0; e < 8; ++e) fw2[a][j][e] = (_Float16)(0.003f * (lane + e));
+  for (int a = 0; a < 2; ++a) { for (int j = 0; j < 4; ++j) for (int e = 0; e < 8; ++e) fa[a][j][e] = (_Float16)(0.001f * (lane + e + j));
+                                for (int j = 0; j < 2; ++j) for (int e = 0; e < 8; ++e) fw[a][j][e] = (_Float16)(0.002f * (lane - e + j)); }
+  int arow[4];
+  for (int t = 0; t < 4; ++t) arow[t] = wm * 128 + t * 32 + frow + 43;
+  int w_off[2][2];
+  for (int t = 0; t < 2; ++t) for (int kk = 0; kk < 2; ++kk) { const int rw = wn * 64 + t * 32 + frow; w_off[t][kk] = rw * ROWB + (((2 * kk + fhalf) ^ swz(rw)) << 4); }
+  const unsigned long long t0 = clock64();
+  for (int tile = 0; tile < tiles_per_wg; ++tile) {
+    const int pbase = ((blockIdx.x * tiles_per_wg + tile) % 4096) * (PATCH_BYTES * 2);
+    if (grp) __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < ksteps; ++s) {
+      const int T = s % 9, cc = s / 9;
+      const unsigned char* pb = patch + (cc & 1) * PATCH_BYTES;
+      const unsigned char* wb = wring + (s & (NSTW - 1)) * W_BYTES;
+      const int shift = (T / 3) * 42 + (T % 3) - 43;
+      if (!MONLY) {
+        auto do_dma = [&]() {
+          if (T < 5) dma16(rsP, patch + ((cc + 1) & 1) * PATCH_BYTES + (wid * 5 + T) * 1024, lane * 16, pbase + (wid * 5 + T) * 1024);   // 40 pieces of 16 rows = 640 rows per chunk
+          dma16(rsW, wring + ((s + 3) & (NSTW - 1)) * W_BYTES + wid * 1024, lane * 16, ((s + 3) % 144) * W_BYTES + wid * 1024);
+        };
+        if (!NODMA && DMAFIRST) do_dma();
+        if (!NOREAD && !RCOMP && !RC2) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            int ar = arow[t]; asm volatile("" : "+v"(ar));
+            const int pr = ar + shift, a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+            fa[0][t] = *reinterpret_cast<const half8*>(pb + a0);
+            fa[1][t] = *reinterpret_cast<const half8*>(pb + (a0 ^ 32));
+          }
+          if (!WLATE) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fw[kk][t] = *reinterpret_cast<const half8*>(wb + w_off[t][kk]);
+          }
+        }
+        if (!NODMA) {
+          if (!DMAFIRST && !DMACOMP) do_dma();
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
+        if (!LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (LATEWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!NOMFMA && RC2) {
+        // every fragment read of k-step s + 1 behind the MFMAs of k-step s, into a SECOND register set (one read after every MFMA pair...)
+        const int s1 = s + 1, T1 = s1 % 9, cc1 = s1 / 9;
+        const unsigned char* pb1 = patch + (cc1 & 1) * PATCH_BYTES;
+        const unsigned char* wb1 = wring + (s1 & (NSTW - 1)) * W_BYTES;
+        const int shift1 = (T1 / 3) * 42 + (T1 % 3) - 43;
+        // the twelve reads right behind the FIRST four MFMAs (their latency runs under the other twelve), then the rest of the MFMAs
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[0][0], fa[0][j], acc[0][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          int ar = arow[t]; asm volatile("" : "+v"(ar));
+          const int pr = ar + shift1, a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+          fa2[0][t] = *reinterpret_cast<const half8*>(pb1 + a0);
+          fa2[1][t] = *reinterpret_cast<const half8*>(pb1 + (a0 ^ 32));
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) fw2[k2][t] = *reinterpret_cast<const half8*>(wb1 + w_off[t][k2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[0][1], fa[0][j], acc[1][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[1][i], fa[1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (!NOMFMA && RCOMP) {
+        // every fragment read of k-step s + 1 behind the MFMAs of k-step s that free its registers: kk = 0 half, then kk = 1 half
+        const int s1 = s + 1, T1 = s1 % 9, cc1 = s1 / 9;
+        const unsigned char* pb1 = patch + (cc1 & 1) * PATCH_BYTES;
+        const unsigned char* wb1 = wring + (s1 & (NSTW - 1)) * W_BYTES;
+        const int shift1 = (T1 / 3) * 42 + (T1 % 3) - 43;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            int ar = arow[t]; asm volatile("" : "+v"(ar));
+            const int pr = ar + shift1, a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+            fa[kk][t] = *reinterpret_cast<const half8*>(pb1 + (kk ? (a0 ^ 32) : a0));
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) fw[kk][t] = *reinterpret_cast<const half8*>(wb1 + w_off[t][kk]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (!NOMFMA) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(fa[0][j]), "v"(fa[1][j]));
+        asm volatile("" :: "v"(fw[0][0]), "v"(fw[0][1]), "v"(fw[1][0]), "v"(fw[1][1]));
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!MONLY && WLATE && !NOREAD) {       // the weight fragments of the NEXT k-step, behind this step's MFMAs (second register set)
+        const unsigned char* wb1 = wring + ((s + 1) & (NSTW - 1)) * W_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) fw2[kk][t] = *reinterpret_cast<const half8*>(wb1 + w_off[t][kk]);
+      }
+      if (!MONLY && DMACOMP && !NODMA) {
+        if (T < 5) dma16(rsP, patch + ((cc + 1) & 1) * PATCH_BYTES + (wid * 5 + T) * 1024, lane * 16, pbase + (wid * 5 + T) * 1024);
+        dma16(rsW, wring + ((s + 3) & (NSTW - 1)) * W_BYTES + wid * 1024, lane * 16, ((s + 3) % 144) * W_BYTES + wid * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (WLATE || RC2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) fw[kk][t] = fw2[kk][t];
+      }
+      if (RC2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fa[kk][t] = fa2[kk][t];
+      }
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const unsigned long long t1 = clock64();
+  float sum = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+  out[blockIdx.x * 512 + tid] = sum;
+  if (tid == 0) atomicAdd(clk, t1 - t0);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void k_ls4(const _Float16* __restrict__ W, const _Float16* __restrict__ P, float* out, unsigned long long* clk, int ksteps, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool MONLY = FLAGS & 1, NODMA = FLAGS & 2, NOREAD = FLAGS & 4;
+  unsigned char* patch = smem; unsigned char* wring = smem + 2 * PATCH_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(W), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(P), 0, 0x7FFFFFFF, 0x00020000);
+  float16_ acc[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  half8 fa[2][2][4], fw[2][2][4];          // [buffer][kk][tile]
+  for (int b = 0; b < 2; ++b) for (int a = 0; a < 2; ++a) for (int j = 0; j < 4; ++j) for (int e = 0; e < 8; ++e) {
+    fa[b][a][j][e] = (_Float16)(0.001f * (lane + e + j)); fw[b][a][j][e] = (_Float16)(0.002f * (lane - e + j)); }
+  int arow[4];
+  for (int t = 0; t < 4; ++t) arow[t] = wid * 128 + t * 32 + frow + 43;
+  int w_off[4][2];
+  for (int t = 0; t < 4; ++t) for (int kk = 0; kk < 2; ++kk) { const int rw = t * 32 + frow; w_off[t][kk] = rw * ROWB + (((2 * kk + fhalf) ^ swz(rw)) << 4); }
+  const unsigned long long t0 = clock64();
+  // one k-step with fragment buffer `cur` multiplied and `cur ^ 1` filled for k-step s + 1
+  auto kstep = [&](int s, int pbase, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value, NXT = CUR ^ 1;
+    const int s1 = s + 1, T1 = s1 % 9, cc1 = s1 / 9, T = s % 9, cc = s / 9;
+    const unsigned char* pb = patch + (cc1 & 1) * PATCH_BYTES;
+    const unsigned char* wb = wring + (s1 & (NSTW - 1)) * W_BYTES;
+    const int shift = (T1 / 3) * 42 + (T1 % 3) - 43;
+    if (!MONLY) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this step's fragments (requested one k-step ago)
+      if (!NODMA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's pieces of the stage read next have landed
+      __builtin_amdgcn_s_barrier();                           // ... everyone's; and everyone is done reading the stage refilled below
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                            // 16 groups of (one fragment read [+ a DMA piece]) + two MFMAs
+      if (!MONLY) {
+        if (!NOREAD) {
+          if (q < 8) {
+            const int t = q >> 1, kk = q & 1;
+            int ar = arow[t]; asm volatile("" : "+v"(ar));
+            const int pr = ar + shift, a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+            fa[NXT][kk][t] = *reinterpret_cast<const half8*>(pb + (kk ? (a0 ^ 32) : a0));
+          } else {
+            const int t = (q - 8) >> 1, kk = q & 1;
+            fw[NXT][kk][t] = *reinterpret_cast<const half8*>(wb + w_off[t][kk]);
+          }
+        }
+        if (!NODMA) {
+          if (q == 2 || q == 6) dma16(rsW, wring + ((s + 3) & (NSTW - 1)) * W_BYTES + (wid * 2 + (q == 6)) * 1024, lane * 16, ((s + 3) % 144) * W_BYTES + (wid * 2 + (q == 6)) * 1024);
+          if (q == 10) dma16(rsP, patch + ((cc + 1) & 1) * PATCH_BYTES + ((wid * 9 + T) % 40) * 1024, lane * 16, pbase + ((wid * 9 + T) % 40) * 1024);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int kk = q >> 3, i = (q >> 1) & 3, j0 = (q & 1) * 2;
+        acc[i][j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[CUR][kk][i], fa[CUR][kk][j0], acc[i][j0], 0, 0, 0);
+        acc[i][j0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[CUR][kk][i], fa[CUR][kk][j0 + 1], acc[i][j0 + 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int tile = 0; tile < tiles_per_wg; ++tile) {
+    const int pbase = ((blockIdx.x * tiles_per_wg + tile) % 4096) * (PATCH_BYTES * 2);
+    for (int s = 0; s < ksteps; s += 2) {
+      kstep(s, pbase, std::integral_constant<int, 0>{});
+      kstep(s + 1, pbase, std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const unsigned long long t1 = clock64();
+  float sum = 0.f;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+  out[blockIdx.x * 256 + tid] = sum;
+  if (tid == 0) atomicAdd(clk, t1 - t0);
+}
+
+template <typename K>
+static void run(const char* name, K kern, int threads, const _Float16* W, const _Float16* P, float* out, unsigned long long* clk) {
+  const int ksteps = 144, tiles = 8, wgs = 256;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemset(clk, 0, 8));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), LDS_BYTES, 0, W, P, out, clk, ksteps, tiles);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c; CK(hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost));
+    const double per = (double)c / wgs / (ksteps * tiles);
+    const double tf = 2.0 * 512 * 128 * 32 * ksteps * tiles * wgs / (ms * 1e-3) / 1e12;
+    if (rep == 2) printf("%-8s %8.1f clk per k-step (1024 = matrix pipe full)  occupancy %.3f   %7.1f TFLOP/s  %.3f ms\n", name, per, 1024.0 / per, tf, ms);
+  }
+}
+
+int main() {
+  _Float16 *W, *P; float* out; unsigned long long* clk;
+  CK(hipMalloc(&W, 144 * W_BYTES + 65536)); CK(hipMalloc(&P, (size_t)4096 * PATCH_BYTES * 2 + 65536)); CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&clk, 8));
+  CK(hipMemset(W, 0x11, 144 * W_BYTES + 65536)); CK(hipMemset(P, 0x12, (size_t)4096 * PATCH_BYTES * 2 + 65536));
+  run("PP8", k_pp8<0>, 512, W, P, out, clk);
+  run("PP8_M", k_pp8<1>, 512, W, P, out, clk);
+  run("PP8_ND", k_pp8<2>, 512, W, P, out, clk);
+  run("PP8_NR", k_pp8<4>, 512, W, P, out, clk);
+  run("PP8_LW", k_pp8<8>, 512, W, P, out, clk);          // lgkmcnt(0) after the barrier instead of in front of it
+  run("PP8_DF", k_pp8<32>, 512, W, P, out, clk);         // LDS-DMA pieces issued before the fragment reads
+  run("PP8_LWDF", k_pp8<40>, 512, W, P, out, clk);
+  run("PP8_MEM", k_pp8<16>, 512, W, P, out, clk);        // no MFMAs: two memory clusters per k-step
+  run("PP8_MEMLW", k_pp8<24>, 512, W, P, out, clk);
+  run("MEM_ND", k_pp8<16 | 2>, 512, W, P, out, clk);     // memory clusters of fragment reads only
+  run("MEM_NR", k_pp8<16 | 4>, 512, W, P, out, clk);     // memory clusters of LDS-DMA only
+  run("PP8_W4", k_pp8<64>, 512, W, P, out, clk);         // the 4 weight-fragment reads of k-step s + 1 behind the MFMAs of k-step s
+  run("PP8_W4LW", k_pp8<64 | 8>, 512, W, P, out, clk);
+  run("PP8_RC2", k_pp8<512>, 512, W, P, out, clk);       // ALL fragment reads of k-step s + 1 behind the MFMAs of k-step s, second register set
+  run("PP8_RC2LW", k_pp8<512 | 8>, 512, W, P, out, clk);
+  run("PP8_RC", k_pp8<256>, 512, W, P, out, clk);        // ALL fragment reads of k-step s + 1 behind the MFMAs of k-step s (same registers)
+  run("PP8_RCLW", k_pp8<256 | 8>, 512, W, P, out, clk);
+  run("PP8_RCND", k_pp8<256 | 2>, 512, W, P, out, clk);
+  run("PP8_DC", k_pp8<128>, 512, W, P, out, clk);        // the LDS-DMA pieces behind the MFMAs (compute cluster)
+  run("PP8_DCW4", k_pp8<128 | 64>, 512, W, P, out, clk);
+  run("PP8_DCLW", k_pp8<128 | 8>, 512, W, P, out, clk);
+  run("LS4", k_ls4<0>, 256, W, P, out, clk);
+  run("LS4_M", k_ls4<1>, 256, W, P, out, clk);
+  run("LS4_ND", k_ls4<2>, 256, W, P, out, clk);
+  run("LS4_NR", k_ls4<4>, 256, W, P, out, clk);
+  return 0;
+}
