@@ -188,6 +188,10 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
   if (grp) __builtin_amdgcn_s_barrier();           // group 1 sits out interval 0
 
   half8 fa[2][TM], fw[2][2];
+  static_assert(TM == 4, "the four fragment addresses of the next tap are computed behind the four MFMA groups of a k-step");
+  int anext[TM];                                   // fragment addresses of the next k-step's tap, inside a patch buffer
+#pragma unroll
+  for (int t = 0; t < TM; ++t) anext[t] = (arow[t] << 6) + ((fhalf ^ swz(arow[t])) << 4);     // tap (0,0) of the first k-step
   // one k-step = (chunk cc, tap T).  LAST: cc is the last chunk (no next patch; the weight prefetch runs dry).
   // vmcnt bookkeeping (loads retire in order): this wave's pieces of W(s+1) must have landed when it leaves the memory
   // cluster; younger and allowed in flight are W(s+2), W(s+3) and the patch pieces issued in this and the previous step.
@@ -199,17 +203,17 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
     const unsigned char* pb = patch + (cc & 1) * SW_PATCH_BYTES;
     const unsigned char* wb = wring + (s & (SW_NSTW - 1)) * W_BYTES;
     const int shift = ky * Wp + kx;
-    // ---- memory cluster
+    // ---- memory cluster.  Round 6: the tap's four fragment addresses (8 vector instructions each) are NOT computed here any more but
+    // behind the MFMAs of the previous k-step (anext, below): the stand-alone probe of this loop (scripts/conv_loop_probe,
+    // profiles/r06_i_conv_loop_probe.log) put the memory cluster at ~610 clk against the partner group's 512 clk of MFMAs, and without
+    // the 32 address instructions at ~535 (matrix-pipe occupancy 0.84 -> 0.96); in the MFMA shadow they are free (<= 5 per MFMA hide)
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      int ar = arow[t];
-      asm volatile("" : "+v"(ar));                 // recompute the 5-instruction address per tap: hoisting the 36 tap
-                                                   // addresses out of the chunk loop (loop invariant) spills registers
-      const int pr = ar + shift;
-      const int a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+      const int a0 = anext[t];
       fa[0][t] = *reinterpret_cast<const half8*>(pb + a0);
       fa[1][t] = *reinterpret_cast<const half8*>(pb + (a0 ^ 32));
     }
+    (void)shift;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -234,13 +238,27 @@ __global__ __launch_bounds__(512, 1) void k_conv_sw(IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- compute cluster
     __builtin_amdgcn_s_setprio(1);
+    {
+      // the NEXT k-step's tap: (T + 1) % 9 -- the patch buffer (chunk parity) is added where the address is used
+      constexpr int TN = (T + 1) % 9, kyn = TN / 3, kxn = TN - 3 * kyn;
+      const int shift_n = kyn * Wp + kxn;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+          // one row tile's address behind each group of four MFMAs (TM == 4 row tiles = the four (kk, i) groups)
+          const int t = kk * 2 + i;                // a constant after unrolling
+          {
+            int ar = arow[t];
+            asm volatile("" : "+v"(ar));           // keep the per-tap recomputation: 36 hoisted tap addresses would spill
+            const int pr = ar + shift_n;
+            anext[t] = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+          }
+        }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();

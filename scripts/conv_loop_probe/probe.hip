@@ -30,7 +30,7 @@ __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 template <int FLAGS>
 __global__ __launch_bounds__(512, 1) void k_pp8(const _Float16* __restrict__ W, const _Float16* __restrict__ P, float* out, unsigned long long* clk, int ksteps, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool MONLY = FLAGS & 1, NODMA = FLAGS & 2, NOREAD = FLAGS & 4, LATEWAIT = FLAGS & 8, NOMFMA = FLAGS & 16, DMAFIRST = FLAGS & 32, WLATE = FLAGS & 64, DMACOMP = FLAGS & 128, RCOMP = FLAGS & 256, RC2 = FLAGS & 512;
+  constexpr bool MONLY = FLAGS & 1, NODMA = FLAGS & 2, NOREAD = FLAGS & 4, LATEWAIT = FLAGS & 8, NOMFMA = FLAGS & 16, DMAFIRST = FLAGS & 32, WLATE = FLAGS & 64, DMACOMP = FLAGS & 128, RCOMP = FLAGS & 256, RC2 = FLAGS & 512, ADDRC = FLAGS & 1024;
   unsigned char* patch = smem; unsigned char* wring = smem + 2 * PATCH_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wid >> 2;
   const int wm = wid >> 1, wn = wid & 1, frow = lane & 31, fhalf = lane >> 5;
@@ -45,6 +45,8 @@ __global__ __launch_bounds__(512, 1) void k_pp8(const _Float16* __restrict__ W, 
                                 for (int j = 0; j < 2; ++j) for (int e = 0; e < 8; ++e) fw[a][j][e] = (_Float16)(0.002f * (lane - e + j)); }
   int arow[4];
   for (int t = 0; t < 4; ++t) arow[t] = wm * 128 + t * 32 + frow + 43;
+  int anext[4];
+  for (int t = 0; t < 4; ++t) { const int pr = arow[t] - 43; anext[t] = (pr << 6) + ((fhalf ^ swz(pr)) << 4); }
   int w_off[2][2];
   for (int t = 0; t < 2; ++t) for (int kk = 0; kk < 2; ++kk) { const int rw = wn * 64 + t * 32 + frow; w_off[t][kk] = rw * ROWB + (((2 * kk + fhalf) ^ swz(rw)) << 4); }
   const unsigned long long t0 = clock64();
@@ -65,8 +67,9 @@ __global__ __launch_bounds__(512, 1) void k_pp8(const _Float16* __restrict__ W, 
         if (!NOREAD && !RCOMP && !RC2) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            int ar = arow[t]; asm volatile("" : "+v"(ar));
-            const int pr = ar + shift, a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+            int a0;
+            if (ADDRC) a0 = anext[t];                      // computed behind the MFMAs of the previous k-step
+            else { int ar = arow[t]; asm volatile("" : "+v"(ar)); const int pr = ar + shift; a0 = (pr << 6) + ((fhalf ^ swz(pr)) << 4); }
             fa[0][t] = *reinterpret_cast<const half8*>(pb + a0);
             fa[1][t] = *reinterpret_cast<const half8*>(pb + (a0 ^ 32));
           }
@@ -140,6 +143,21 @@ __global__ __launch_bounds__(512, 1) void k_pp8(const _Float16* __restrict__ W, 
           for (int t = 0; t < 2; ++t) fw[kk][t] = *reinterpret_cast<const half8*>(wb1 + w_off[t][kk]);
           __builtin_amdgcn_sched_barrier(0);
         }
+      } else if (!NOMFMA && ADDRC) {
+        // the four tap addresses of k-step s + 1 (8 vector instructions each) in the shadow of this step's MFMAs: one row tile per four MFMAs
+        const int s1 = s + 1, T1 = s1 % 9;
+        const int shift1 = (T1 / 3) * 42 + (T1 % 3) - 43;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+            const int t = kk * 2 + i;
+            int ar = arow[t]; asm volatile("" : "+v"(ar));
+            const int pr = ar + shift1;
+            anext[t] = (pr << 6) + ((fhalf ^ swz(pr)) << 4);
+          }
       } else if (!NOMFMA) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -303,6 +321,10 @@ int main() {
   run("MEM_NR", k_pp8<16 | 4>, 512, W, P, out, clk);     // memory clusters of LDS-DMA only
   run("PP8_W4", k_pp8<64>, 512, W, P, out, clk);         // the 4 weight-fragment reads of k-step s + 1 behind the MFMAs of k-step s
   run("PP8_W4LW", k_pp8<64 | 8>, 512, W, P, out, clk);
+  run("PP8_AC", k_pp8<1024>, 512, W, P, out, clk);       // the tap addresses of k-step s + 1 computed behind the MFMAs of k-step s
+  run("PP8_ACLW", k_pp8<1024 | 8>, 512, W, P, out, clk);
+  run("PP8_ACW4", k_pp8<1024 | 64>, 512, W, P, out, clk);
+  run("PP8_ACW4LW", k_pp8<1024 | 64 | 8>, 512, W, P, out, clk);
   run("PP8_RC2", k_pp8<512>, 512, W, P, out, clk);       // ALL fragment reads of k-step s + 1 behind the MFMAs of k-step s, second register set
   run("PP8_RC2LW", k_pp8<512 | 8>, 512, W, P, out, clk);
   run("PP8_RC", k_pp8<256>, 512, W, P, out, clk);        // ALL fragment reads of k-step s + 1 behind the MFMAs of k-step s (same registers)
