@@ -1,6 +1,7 @@
 #!/bin/bash
 # ONE parameterised GPU-box script (replaces the fifty single-use scripts/gpu_r*_*.sh of rounds 2-4):
 #   gpurun --timeout 1500 -- 'TAG=r05_a bash scripts/gpu.sh sane tests bench prof pmc track smoke'
+#   (round 6: + trace, abengine, trained, render, convprobe; the round's closing records = sane tests smoke bench prof pmc trace)
 # Every task writes gpurun_out/${TAG}_<task>.*; summaries worth keeping are copied into profiles/ by hand afterwards.
 export TMPDIR=/tmp
 TAG=${TAG:-r05}
@@ -118,6 +119,30 @@ t_track() {
 }
 t_smoke() {
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | cut -c1-400
+}
+t_trace() {   # kernel trace of the default (two-stream, graph-replay) command -> scripts/concurrent_roofline.py
+  timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -o bench -- python bench.py --trace-markers --no-kernel-table --no-cpu-baseline --no-extras > $O/${TAG}_bench_traced.json 2> /dev/null
+  local T=$(ls $O/${TAG}_trace/*kernel_trace.csv $O/${TAG}_trace/*/*kernel_trace.csv 2>/dev/null | head -1)
+  python scripts/concurrent_roofline.py "$T" $O/${TAG}_bench_traced.json > $O/${TAG}_concurrent_roofline.json 2> /dev/null; python -c "import json; d = json.load(open('$O/${TAG}_concurrent_roofline.json')); print(d['roofline_concurrent'], d['idle_frac'])"
+  rm -rf $O/${TAG}_trace
+}
+t_abengine() {   # ENGINE_AB="name:SWITCH=0,SWITCH=0 name2: ...": same-box A/B of engine.py switches (bench.py FP_BENCH_ENGINE)
+  for v in $ENGINE_AB; do
+    local name=${v%%:*} eng=${v#*:}
+    FP_BENCH_ENGINE="$eng" bench_line $name $PWD/$CS/libfp_amd.so
+  done
+}
+t_trained() {    # the trained stand-in against its exactly-rounded chain + the one-hypothesis small-call path
+  FP_PARITY_REPORT=${TAG}_parity_trained.json timeout 1500 python -m pytest tests/test_gpu_amp.py -q --timeout 1200 -k "trained_standin or track_one_small_call" 2>&1 | tail -3 | cut -c1-300
+}
+t_render() {     # fp_render_crops alone (LIBS="product ..."): us per launch + output digests
+  for name in ${LIBS:-product}; do
+    local lib=$PWD/$CS/libfp_amd_$name.so; [ $name = product ] && lib=$PWD/$CS/libfp_amd.so
+    echo "-- $name"; FP_AMD_LIB=$lib timeout 120 python scripts/bench_render.py 2>&1 | tail -4
+  done
+}
+t_convprobe() {  # stand-alone replica of the conv main loop (scripts/conv_loop_probe): short (clocks per k-step), long with random operands (power cap)
+  hipcc --offload-arch=gfx950 -O3 -o /tmp/cvprobe scripts/conv_loop_probe/probe.hip && { timeout 200 /tmp/cvprobe; timeout 300 /tmp/cvprobe 2000; timeout 300 /tmp/cvprobe 2000 random; } | tee $O/${TAG}_conv_loop_probe.log
 }
 for task in "$@"; do
   el "$task"
