@@ -327,7 +327,8 @@ int main(int argc, char** argv) {
     printf("operands: random (weights N(0, 0.02), activations relu(N(0, 0.5)))\n");
   }
   if (g_tiles > 100) {      // long launches: the three that matter, twice
-    for (int r = 0; r < 2; ++r) { run("PP8", k_pp8<0>, 512, W, P, out, clk); run("PP8_AC", k_pp8<1024>, 512, W, P, out, clk); run("PP8_M", k_pp8<1>, 512, W, P, out, clk); }
+    for (int r = 0; r < 2; ++r) { run("PP8", k_pp8<0>, 512, W, P, out, clk); run("PP8_AC", k_pp8<1024>, 512, W, P, out, clk); run("PP8_M", k_pp8<1>, 512, W, P, out, clk);
+                                  run("LS4", k_ls4<0>, 256, W, P, out, clk); run("LS4_M", k_ls4<1>, 256, W, P, out, clk); run("PP8_NR", k_pp8<4>, 512, W, P, out, clk); run("PP8_ND", k_pp8<2>, 512, W, P, out, clk); }
     return 0;
   }
   run("PP8", k_pp8<0>, 512, W, P, out, clk);
