@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA
+MFMA_ONLY_UNDER_CAP_TFLOPS = 1800.0   # measured: MFMA-only loop, lane-dependent fp16 operands, 1.4 kW cap (profiles/r06_i_conv_loop_probe.log)
 REFINE_GFLOP_PER_HYP = 23.946
 SCORE_GFLOP_PER_HYP = 21.938
 SCORE_GFLOP_CROSS_252 = 0.659
@@ -705,6 +706,15 @@ def main():
                                                        "frac_concurrent": (out["roofline"]["concurrent"]["achieved"] / pk)
                                                        if "concurrent" in out["roofline"] else None,
                                                        "note": "peak x sclk / 2400 MHz; `frac` above stays against the datasheet peak"}
+            if bound == "mfma":
+                # round 6 (scripts/conv_loop_probe, profiles/r06_i_conv_loop_probe.log): what the 1.4 kW cap leaves an fp16 MFMA kernel on
+                # non-trivial operand data on this chip -- a register-resident MFMA-ONLY loop on lane-dependent data sustains 1.80 PFLOP/s
+                # (1.72 GHz), the convolution main loop with its LDS / LDS-DMA traffic 1.50-1.55.  A committed measurement, not a peak.
+                out["roofline"]["under_power_cap"] = {
+                    "mfma_only_sustained": MFMA_ONLY_UNDER_CAP_TFLOPS, "conv_main_loop_sustained": 1550.0, "unit": unit,
+                    "frac_of_mfma_only_sustained": ach / MFMA_ONLY_UNDER_CAP_TFLOPS,
+                    "source": "profiles/r06_i_conv_loop_probe.log (scripts/conv_loop_probe/probe.hip 2000 random)",
+                    "note": "`frac` above stays against the 2.5 PFLOP/s datasheet peak"}
             out["stage_raster_crop"] = {"bytes_per_pass": stage_bytes, "ms_per_pass": r_ms + w_ms,
                                         "achieved_GBps": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9,
                                         "frac_of_hbm_peak": stage_bytes / ((r_ms + w_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
